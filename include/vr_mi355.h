@@ -1,0 +1,104 @@
+/* libvr_mi355.so -- C ABI of the MI355X-native vocal-remover hot path.
+ *
+ * The reference (tsurumeso/vocal-remover @ 2024_08_07) has no FFI layer: its boundary is the Python
+ * API that inference.py / train.py / pseudo.py call.  Each entry point below names the reference
+ * interface it replaces; vocal-remover_amd/ binds them with ctypes and re-exposes the reference's
+ * class / function names.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative vr_status; the message of the last failure
+ *     on the calling thread is vr_last_error().  Nothing aborts, nothing calls back into the host.
+ *   - `*_on_device` flags say whether a data pointer is host memory (numpy / torch CPU,
+ *     C-contiguous) or device memory on the handle's GPU.  The caller owns every pointer it passes;
+ *     the library copies.  The library owns all device memory it allocates (weights, workspace).
+ *   - a handle is bound to one GPU and one HIP stream and is not thread-safe; use one handle per
+ *     process per GPU.  Calls return after the handle's stream has drained.
+ *   - tensors are fp32; spectrograms are complex64 stored as interleaved (re, im) floats with the
+ *     reference's layout [2, n_fft/2+1, frames]; waves are [2, samples].
+ */
+#ifndef VR_MI355_H
+#define VR_MI355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vr_model* vr_handle;
+
+enum vr_status {
+    VR_OK = 0,
+    VR_ERR_UNKNOWN = -1,
+    VR_ERR_BAD_ARGUMENT = -2,   /* shape / key / flag errors                                      */
+    VR_ERR_HIP = -3,            /* a HIP runtime call failed                                       */
+    VR_ERR_OOM = -4,            /* workspace planning / allocation failure                         */
+    VR_ERR_CROP_CENTER = -5,    /* reference ValueError of spec_utils.crop_center (spec_utils.py:15) */
+    VR_ERR_EMPTY_MASK = -6      /* reference `assert mask.size()[3] > 0` (nets.py:129,139)         */
+};
+
+const char* vr_last_error(void);
+
+/* nets.CascadedNet(n_fft, hop_length, nout=32, nout_lstm=128)        lib/nets.py:46-80
+ * (is_complex=False, the only configuration any reference caller uses).                           */
+int vr_create(int device, int n_fft, int hop_length, int nout, int nout_lstm, vr_handle* out);
+int vr_destroy(vr_handle h);
+
+/* nn.Module.state_dict() / load_state_dict()                  inference.py:131, train.py:209,290
+ * One call per state-dict key (689 keys for the default net), torch shapes and layouts
+ * (conv OIHW, LSTM [4H, I], gate order i,f,g,o).  num_batches_tracked entries are int64.        */
+int vr_num_params(vr_handle h);
+int vr_param_info(vr_handle h, int index, char* key_buf, int key_cap, int64_t* shape4, int* ndim,
+                  int* is_int64, int* trainable);
+int vr_set_param(vr_handle h, const char* key, const void* host, const int64_t* shape, int ndim);
+int vr_get_param(vr_handle h, const char* key, void* host, int64_t capacity_bytes);
+
+/* nn.Module.train() / eval()                                          inference.py:52, train.py:69,109 */
+int vr_set_mode(vr_handle h, int training);
+
+/* CascadedNet.forward (mode 0) / predict_mask (mode 1) / predict (mode 2)   lib/nets.py:82-141
+ * x:   [B, 2, n_fft/2+1, T] fp32 magnitudes
+ * out: mode 0 [B,2,bins,T];  modes 1,2 [B,2,bins,T-128]                                          */
+int vr_forward(vr_handle h, const float* x, int x_on_device, int B, int T, int mode, float* out,
+               int out_on_device);
+
+/* spec_utils.wave_to_spectrogram(wave, hop_length, n_fft)          lib/spec_utils.py:26-31
+ * wave [2, L] -> spec [2, bins, 1 + L/hop] complex64                                              */
+int vr_stft(vr_handle h, const float* wave, int wave_on_device, int64_t L, float* spec, int spec_on_device);
+
+/* spec_utils.spectrogram_to_wave(spec, hop_length)                 lib/spec_utils.py:157-165
+ * spec [2, bins, T] -> wave [2, hop*(T-1)]                                                        */
+int vr_istft(vr_handle h, const float* spec, int spec_on_device, int T, float* wave, int wave_on_device);
+
+/* Separator(model, device, batchsize, cropsize).separate / separate_tta     inference.py:70-102
+ * spec [2,bins,T] complex64 -> y_spec (instruments), v_spec (vocals), same shape.
+ * batchsize <= 0: all crops of a pass in one device batch.                                        */
+int vr_separate(vr_handle h, const float* spec, int spec_on_device, int T, int tta, int batchsize,
+                int cropsize, float* y_spec, float* v_spec, int out_on_device);
+
+/* The whole of inference.py:147-176 in one device-resident call:
+ * wave_to_spectrogram -> Separator.separate[_tta] -> spectrogram_to_wave x2.
+ * wave [2, L] -> y_wave, v_wave [2, hop*(L/hop)]                                                  */
+int vr_separate_wave(vr_handle h, const float* wave, int wave_on_device, int64_t L, int tta, int batchsize,
+                     int cropsize, float* y_wave, float* v_wave, int out_on_device);
+
+/* ---- measurement hooks (bench.py) ----------------------------------------------------------- */
+/* Bracket subsequent calls: every MFMA-conv launch is timed with HIP events on the handle's stream. */
+int vr_profile_begin(vr_handle h);
+int vr_profile_end(vr_handle h, double* conv_ms, double* conv_flops, int* conv_launches);
+
+/* ---- test hooks (tests/ only) ---------------------------------------------------------------- */
+/* One convolution through the MFMA kernel: x [N,Cin,H,W] (optionally x2-upsampled, optionally with
+ * a pending per-channel affine [Cin][2] + activation slope), w OIHW, padding = dilation (3x3) or 0
+ * (1x1).  stats_out [Cout][2] receives (sum, sumsq) of the output per channel when non-null.      */
+int vr_debug_conv2d(vr_handle h, const float* x, int N, int Cin, int H, int W, const float* w, int Cout,
+                    int ksize, int stride, int dil_h, int dil_w, int upsample, const float* affine,
+                    float slope, const float* bias, float* out, float* stats_out);
+/* Record intermediate activations of the next vr_forward and read them back (post-activation). */
+int vr_debug_record_taps(vr_handle h, int enable);
+int64_t vr_debug_get_tap(vr_handle h, const char* name, float* host, int64_t capacity_floats, int64_t* shape4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VR_MI355_H */

@@ -132,6 +132,14 @@ def lstm_module(x, sd, p, **kw):
 
 DILATIONS = ((4, 2), (8, 4), (12, 6))
 
+# Set to a dict to record intermediate activations (test diagnostics): keys '<net prefix>.e1' ...
+TAPS = None
+
+
+def _tap(name, t):
+    if TAPS is not None:
+        TAPS[name] = t.detach().clone()
+
 
 def base_net(x, sd, p, dropout=None, **kw):
     """nets.BaseNet, lib/nets.py:8-41."""
@@ -140,12 +148,22 @@ def base_net(x, sd, p, dropout=None, **kw):
     e3 = encoder(e2, sd, p + '.enc3', 2, **kw)
     e4 = encoder(e3, sd, p + '.enc4', 2, **kw)
     e5 = encoder(e4, sd, p + '.enc5', 2, **kw)
+    for i, e in enumerate((e1, e2, e3, e4, e5)):
+        _tap('%s.e%d' % (p, i + 1), e)
     h = aspp(e5, sd, p + '.aspp', DILATIONS, dropout=None if dropout is None else dropout.get(p + '.aspp'), **kw)
+    _tap(p + '.aspp', h)
     h = decoder(h, e4, sd, p + '.dec4', **kw)
+    _tap(p + '.dec4', h)
     h = decoder(h, e3, sd, p + '.dec3', **kw)
+    _tap(p + '.dec3', h)
     h = decoder(h, e2, sd, p + '.dec2', **kw)
-    h = torch.cat([h, lstm_module(h, sd, p + '.lstm_dec2', **kw)], dim=1)
-    return decoder(h, e1, sd, p + '.dec1', **kw)
+    _tap(p + '.dec2', h)
+    lo = lstm_module(h, sd, p + '.lstm_dec2', **kw)
+    _tap(p + '.lstm', lo)
+    h = torch.cat([h, lo], dim=1)
+    h = decoder(h, e1, sd, p + '.dec1', **kw)
+    _tap(p + '.dec1', h)
+    return h
 
 
 BASE_NETS = ('stg1_low_band_net.0', 'stg1_high_band_net', 'stg2_low_band_net.0',

@@ -1,0 +1,260 @@
+"""GPU parity tests (run with -m gpu on an MI355X): HIP path through the C ABI vs the CPU oracle.
+
+Tolerances (fp32, stated per test):
+  * single conv launch vs torch.nn.functional.conv2d:        1e-4 * max|ref| (K up to 2304)
+  * predict_mask / forward mask in [0,1]:                    max-abs 1e-4, mean-abs 1e-5
+  * STFT vs float64 restatement:                             2e-5 * max|X|;   iSTFT 2e-5 abs
+  * Separator y/v spectrograms:                              1e-4 * max|X|
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import cascaded_net, separator, stft_np, weights
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def small(vr):
+    n_fft, nout, nout_lstm = 512, 8, 32
+    sd = weights.make_state_dict(11, n_fft=n_fft, nout=nout, nout_lstm=nout_lstm)
+    model = vr.nets.CascadedNet(n_fft, n_fft // 2, nout, nout_lstm)
+    model.load_state_dict(sd)
+    model.to(torch.device('cuda:0'))
+    model.eval()
+    return model, sd, n_fft
+
+
+def _conv_case(vr, handle, N, Cin, H, W, Cout, ks, stride, dh, dw, up, use_aff, slope, use_bias, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / (Cin * ks * ks) ** 0.5
+    aff = torch.stack([torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3], 1) if use_aff else None
+    bias = torch.randn(Cout, generator=g) if use_bias else None
+    xin = x
+    if aff is not None:
+        xin = xin * aff[:, 0].view(1, -1, 1, 1) + aff[:, 1].view(1, -1, 1, 1)
+    xin = torch.where(xin > 0, xin, xin * slope)
+    if up:
+        xin = F.interpolate(xin, scale_factor=2, mode='bilinear', align_corners=True)
+    pad = (dh, dw) if ks == 3 else (0, 0)
+    want = F.conv2d(xin, w, bias, stride, pad, (dh, dw))
+    got = np.empty(tuple(want.shape), np.float32)
+    stats = np.empty((Cout, 2), np.float32)
+    xn, wn = x.numpy(), w.numpy()
+    an = aff.numpy().copy() if aff is not None else None
+    bn = bias.numpy() if bias is not None else None
+    nat = vr.native
+    nat.check(nat.lib().vr_debug_conv2d(
+        handle.h, nat.np_ptr(xn), N, Cin, H, W, nat.np_ptr(wn), Cout, ks, stride, dh, dw, int(up),
+        nat.np_ptr(an) if an is not None else None, ctypes.c_float(slope),
+        nat.np_ptr(bn) if bn is not None else None, nat.np_ptr(got), nat.np_ptr(stats)))
+    scale = float(want.abs().max())
+    err = float(np.abs(got - want.numpy()).max())
+    s1 = want.sum(dim=(0, 2, 3)).numpy()
+    s2 = (want.double() ** 2).sum(dim=(0, 2, 3)).numpy()
+    e1 = float(np.abs(stats[:, 0] - s1).max() / (np.abs(s1).max() + 1.0))
+    e2 = float(np.abs(stats[:, 1] - s2).max() / (np.abs(s2).max() + 1.0))
+    return err / scale, e1, e2
+
+
+CONV_CASES = [
+    # N, Cin, H,  W,  Cout, ks, stride, dh, dw, up, aff, slope, bias
+    (2, 2, 16, 32, 16, 3, 1, 1, 1, 0, 0, 1.0, 0),
+    (1, 10, 24, 64, 32, 3, 1, 1, 1, 0, 1, 0.0, 0),
+    (2, 26, 40, 48, 32, 3, 1, 1, 1, 0, 1, 0.01, 0),      # W not a multiple of 32
+    (1, 64, 16, 32, 64, 3, 1, 1, 1, 0, 1, 0.0, 0),
+    (1, 32, 32, 64, 128, 3, 1, 1, 1, 0, 1, 0.0, 0),
+    (3, 17, 20, 16, 48, 3, 1, 1, 1, 0, 1, 0.0, 0),       # TW=16 tiles, odd Cin, Cout=48
+    (2, 16, 32, 64, 32, 3, 2, 1, 1, 0, 1, 0.01, 0),      # stride 2
+    (1, 33, 34, 36, 96, 3, 2, 1, 1, 0, 1, 0.01, 0),
+    (2, 8, 32, 16, 8, 3, 2, 1, 1, 0, 0, 1.0, 0),
+    (2, 32, 32, 16, 32, 3, 1, 4, 2, 0, 1, 0.0, 0),       # ASPP dilations
+    (1, 64, 64, 16, 64, 3, 1, 8, 4, 0, 1, 0.0, 0),
+    (2, 16, 32, 16, 16, 3, 1, 12, 6, 0, 1, 0.0, 0),
+    (2, 40, 16, 32, 8, 1, 1, 1, 1, 0, 1, 0.0, 0),        # 1x1
+    (1, 320, 32, 16, 64, 1, 1, 1, 1, 0, 1, 0.0, 1),      # 1x1 with bias, K=320
+    (1, 128, 5, 64, 256, 1, 1, 1, 1, 0, 0, 1.0, 1),
+    (2, 12, 8, 16, 32, 3, 1, 1, 1, 1, 1, 0.0, 0),        # fused bilinear x2 upsample
+    (1, 24, 16, 24, 16, 3, 1, 1, 1, 1, 1, 0.0, 0),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_conv_kernel_vs_torch(vr, small, case):
+    model = small[0]
+    rel, e1, e2 = _conv_case(vr, model._handle, *case, seed=hash(case) % 1000)
+    assert rel < 1e-4, 'conv max-abs/scale = %.3e' % rel
+    assert e1 < 1e-4 and e2 < 1e-4, 'BatchNorm partial sums off: %.3e %.3e' % (e1, e2)
+
+
+def test_forward_taps_small_net(vr, small):
+    """Every recorded intermediate of the small net vs the oracle's (localises a broken layer)."""
+    model, sd, n_fft = small
+    nat = vr.native
+    x = torch.rand(2, 2, n_fft // 2 + 1, 160, generator=torch.Generator().manual_seed(0))
+    cascaded_net.TAPS = {}
+    with torch.no_grad():
+        want = cascaded_net.forward(x, sd, n_fft=n_fft)
+    taps = cascaded_net.TAPS
+    cascaded_net.TAPS = None
+    nat.check(nat.lib().vr_debug_record_taps(model._handle.h, 1))
+    got = model.forward(x.to('cuda:0')).cpu()
+    report, bad = [], []
+    for name, ref in taps.items():
+        shape = (ctypes.c_int64 * 4)()
+        n = nat.lib().vr_debug_get_tap(model._handle.h, name.encode(), None, 0, shape)
+        assert n > 0, name
+        buf = np.empty(tuple(int(s) for s in shape), np.float32)
+        nat.lib().vr_debug_get_tap(model._handle.h, name.encode(), nat.np_ptr(buf), buf.size, shape)
+        if tuple(buf.shape) != tuple(ref.shape):
+            bad.append('%s shape %s vs %s' % (name, buf.shape, tuple(ref.shape)))
+            continue
+        err = float(np.abs(buf - ref.numpy()).max())
+        scale = float(ref.abs().max()) + 1e-6
+        report.append('%-40s err %.3e scale %.3e' % (name, err, scale))
+        if err > 2e-4 * scale + 1e-5:
+            bad.append(report[-1])
+    nat.check(nat.lib().vr_debug_record_taps(model._handle.h, 0))
+    print('\n'.join(report))
+    assert not bad, '\n'.join(bad)
+    assert float((got - want).abs().max()) < 1e-4
+
+
+def test_predict_variants_small_net(small):
+    model, sd, n_fft = small
+    x = torch.rand(3, 2, n_fft // 2 + 1, 144, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        want_m = cascaded_net.predict_mask(x, sd, n_fft=n_fft)
+        want_p = cascaded_net.predict(x, sd, n_fft=n_fft)
+        want_f = cascaded_net.forward(x, sd, n_fft=n_fft)
+    for dev in ('cuda:0', 'cpu'):
+        xin = x.to(dev)
+        got_m, got_p, got_f = model.predict_mask(xin), model.predict(xin), model(xin)
+        assert got_m.device.type == torch.device(dev).type
+        assert got_m.shape == want_m.shape == (3, 2, n_fft // 2 + 1, 16)
+        assert float((got_m.cpu() - want_m).abs().max()) < 1e-4
+        assert float((got_p.cpu() - want_p).abs().max()) < 1e-4
+        assert float((got_f.cpu() - want_f).abs().max()) < 1e-4
+    # replicate-pad row (lib/nets.py:111-115)
+    assert torch.equal(got_f[:, :, -1], got_f[:, :, -2])
+
+
+def test_reference_error_behaviour(small):
+    model, sd, n_fft = small
+    with pytest.raises(ValueError):        # crop_center ValueError (frames not a multiple of 16)
+        model.predict_mask(torch.rand(1, 2, n_fft // 2 + 1, 152))
+    with pytest.raises(AssertionError):    # assert mask.size()[3] > 0
+        model.predict_mask(torch.rand(1, 2, n_fft // 2 + 1, 128))
+    with pytest.raises(ValueError):
+        model.predict_mask(torch.rand(1, 2, 100, 160))
+
+
+def test_state_dict_roundtrip(small):
+    model, sd, _ = small
+    model._host_stale = True
+    back = model.state_dict()
+    assert list(back.keys()) == list(sd.keys())
+    for k in sd:
+        assert torch.equal(back[k], sd[k]), k
+
+
+@pytest.fixture(scope='module')
+def full(vr):
+    sd = weights.make_state_dict(1234)
+    model = vr.nets.CascadedNet(2048, 1024, 32, 128)
+    model.load_state_dict(sd)
+    model.to(torch.device('cuda:0'))
+    model.eval()
+    return model, sd
+
+
+def test_predict_mask_full_net(full):
+    """The flagship configuration: CascadedNet(2048,1024,32,128), B=2 crops of 256 frames."""
+    model, sd = full
+    x = torch.rand(2, 2, 1025, 256, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        want = cascaded_net.predict_mask(x, sd)
+    got = model.predict_mask(x.to('cuda:0')).cpu()
+    diff = (got - want).abs()
+    print('full net: max-abs %.3e mean-abs %.3e mask std %.3f' % (float(diff.max()), float(diff.mean()), float(want.std())))
+    assert got.shape == (2, 2, 1025, 128)
+    assert float(diff.max()) < 1e-4 and float(diff.mean()) < 1e-5
+    assert float(want.std()) > 0.02
+
+
+def test_batch_independence_full_net(full):
+    """Eval-mode crops are independent (inference.py:44-48): batching must not change results."""
+    model, _ = full
+    x = torch.rand(3, 2, 1025, 256, generator=torch.Generator().manual_seed(3)).to('cuda:0')
+    all3 = model.predict_mask(x)
+    one = model.predict_mask(x[1:2].contiguous())
+    assert float((all3[1:2] - one).abs().max()) < 1e-6
+
+
+def test_stft_istft_vs_oracle(vr):
+    wave = separator.synth_wave(3.0, seed=4)
+    want = stft_np.wave_to_spectrogram(wave, 1024, 2048)
+    got = vr.spec_utils.wave_to_spectrogram(wave, 1024, 2048)
+    assert got.shape == want.shape and got.dtype == np.complex64
+    assert np.abs(got - want).max() < 2e-5 * np.abs(want).max()
+    back_want = stft_np.spectrogram_to_wave(want, 1024)
+    back = vr.spec_utils.spectrogram_to_wave(want, hop_length=1024)
+    assert back.shape == back_want.shape and back.dtype == np.float32
+    assert np.abs(back - back_want).max() < 2e-5
+    # round trip property at any size: istft(stft(x)) == x away from the trimmed tail
+    assert np.abs(back - wave[:, :back.shape[1]]).max() < 2e-5
+    mono = vr.spec_utils.spectrogram_to_wave(want[0], hop_length=1024)
+    assert np.abs(mono - back_want[0]).max() < 2e-5
+
+
+def test_stft_ragged_lengths(vr):
+    for L in (1024, 1500, 4096 + 17):
+        wave = separator.synth_wave(L / 44100.0, seed=L)[:, :L]
+        want = stft_np.wave_to_spectrogram(wave, 1024, 2048)
+        got = vr.spec_utils.wave_to_spectrogram(wave, 1024, 2048)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() < 2e-5 * max(np.abs(want).max(), 1.0)
+
+
+@pytest.mark.parametrize('tta', [False, True])
+def test_separator_small_net(vr, small, tta):
+    model, sd, n_fft = small
+    rng = np.random.default_rng(5)
+    T = 300
+    X = (rng.standard_normal((2, n_fft // 2 + 1, T)) + 1j * rng.standard_normal((2, n_fft // 2 + 1, T))).astype(np.complex64)
+    want_y, want_v = separator.separate(X.copy(), sd, tta=tta, n_fft=n_fft, batchsize=2, cropsize=160)
+    for bs in (2, 0):
+        sp = vr.inference.Separator(model, torch.device('cuda:0'), batchsize=bs, cropsize=160)
+        got_y, got_v = (sp.separate_tta if tta else sp.separate)(X.copy())
+        assert got_y.shape == want_y.shape and got_y.dtype == np.complex64
+        scale = np.abs(X).max()
+        assert np.abs(got_y - want_y).max() < 1e-4 * scale
+        assert np.abs(got_v - want_v).max() < 1e-4 * scale
+        # size-independent property: the two stems sum back to the mixture
+        assert np.abs(got_y + got_v - X).max() < 1e-5 * scale
+
+
+def test_separate_wave_pipeline(vr, small):
+    """STFT -> separate -> iSTFT x2 in one device-resident call equals the staged calls."""
+    model, sd, n_fft = small
+    hop = n_fft // 2
+    wave = separator.synth_wave(1.0, seed=6)[:, :hop * 200 + 13]
+    sp = vr.inference.Separator(model, torch.device('cuda:0'), batchsize=0, cropsize=160)
+    spec = vr.spec_utils.wave_to_spectrogram(wave, hop, n_fft)
+    y_spec, v_spec = sp.separate(spec)
+    y_want = vr.spec_utils.spectrogram_to_wave(y_spec, hop_length=hop)
+    v_want = vr.spec_utils.spectrogram_to_wave(v_spec, hop_length=hop)
+    y, v = sp.separate_wave(wave)
+    assert y.shape == y_want.shape
+    assert np.abs(y - y_want).max() < 1e-5 and np.abs(v - v_want).max() < 1e-5
+    yt, vt = sp.separate_wave(torch.from_numpy(wave).to('cuda:0'))
+    assert np.abs(yt.cpu().numpy() - y).max() < 1e-6
+    # oracle for the whole chain
+    spec_o = stft_np.wave_to_spectrogram(wave, hop, n_fft)
+    yo, vo = separator.separate(spec_o, sd, n_fft=n_fft, batchsize=4, cropsize=160)
+    assert np.abs(y - stft_np.spectrogram_to_wave(yo.astype(np.complex64), hop)).max() < 1e-4

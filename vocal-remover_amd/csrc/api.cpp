@@ -1,0 +1,183 @@
+// extern "C" surface of libvr_mi355.so (include/vr_mi355.h).  Exceptions stop here.
+#include "../../include/vr_mi355.h"
+
+#include <cstring>
+#include <new>
+
+#include "model.h"
+
+struct vr_model {
+    vr::Model m;
+    vr_model(int d, int n, int h, int o, int l) : m(d, n, h, o, l) {}
+};
+
+static thread_local std::string g_err;
+
+template <class F>
+static int guard(F&& f) {
+    try {
+        f();
+        return VR_OK;
+    } catch (const vr::Error& e) {
+        g_err = e.what();
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        g_err = "host allocation failed";
+        return VR_ERR_OOM;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return VR_ERR_UNKNOWN;
+    } catch (...) {
+        g_err = "unknown error";
+        return VR_ERR_UNKNOWN;
+    }
+}
+
+#define NEED(h)                                                  \
+    if (!(h)) {                                                  \
+        g_err = "null handle";                                   \
+        return VR_ERR_BAD_ARGUMENT;                              \
+    }
+
+extern "C" {
+
+const char* vr_last_error(void) { return g_err.c_str(); }
+
+int vr_create(int device, int n_fft, int hop_length, int nout, int nout_lstm, vr_handle* out) {
+    if (!out) { g_err = "null out pointer"; return VR_ERR_BAD_ARGUMENT; }
+    *out = nullptr;
+    return guard([&] {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+            throw vr::Error(VR_ERR_HIP, "no HIP device visible: libvr_mi355 has no CPU fallback");
+        if (device < 0 || device >= count) throw vr::Error(VR_ERR_BAD_ARGUMENT, "device index out of range");
+        *out = new vr_model(device, n_fft, hop_length, nout, nout_lstm);
+    });
+}
+
+int vr_destroy(vr_handle h) {
+    NEED(h);
+    return guard([&] { delete h; });
+}
+
+int vr_num_params(vr_handle h) {
+    if (!h) return VR_ERR_BAD_ARGUMENT;
+    return (int)h->m.params.size();
+}
+
+int vr_param_info(vr_handle h, int index, char* key_buf, int key_cap, int64_t* shape4, int* ndim, int* is_int64,
+                  int* trainable) {
+    NEED(h);
+    return guard([&] {
+        VR_CHECK(index >= 0 && index < (int)h->m.params.size(), VR_ERR_BAD_ARGUMENT, "param index out of range");
+        const vr::Param& p = h->m.params[index];
+        if (key_buf) {
+            VR_CHECK((int)p.key.size() + 1 <= key_cap, VR_ERR_BAD_ARGUMENT, "key buffer too small");
+            std::memcpy(key_buf, p.key.c_str(), p.key.size() + 1);
+        }
+        if (ndim) *ndim = (int)p.shape.size();
+        if (shape4)
+            for (size_t i = 0; i < p.shape.size() && i < 4; ++i) shape4[i] = p.shape[i];
+        if (is_int64) *is_int64 = p.kind == vr::PK_NBT;
+        if (trainable) *trainable = p.trainable;
+    });
+}
+
+int vr_set_param(vr_handle h, const char* key, const void* host, const int64_t* shape, int ndim) {
+    NEED(h);
+    return guard([&] {
+        VR_CHECK(key && host && (shape || ndim == 0), VR_ERR_BAD_ARGUMENT, "null argument");
+        h->m.set_param(key, host, shape, ndim);
+    });
+}
+
+int vr_get_param(vr_handle h, const char* key, void* host, int64_t capacity_bytes) {
+    NEED(h);
+    return guard([&] {
+        VR_CHECK(key && host, VR_ERR_BAD_ARGUMENT, "null argument");
+        h->m.get_param(key, host, capacity_bytes);
+    });
+}
+
+int vr_set_mode(vr_handle h, int training) {
+    NEED(h);
+    return guard([&] { h->m.set_training(training != 0); });
+}
+
+int vr_forward(vr_handle h, const float* x, int x_on_device, int B, int T, int mode, float* out, int out_on_device) {
+    NEED(h);
+    return guard([&] {
+        VR_CHECK(x && out, VR_ERR_BAD_ARGUMENT, "null argument");
+        VR_CHECK(mode >= 0 && mode <= 2, VR_ERR_BAD_ARGUMENT, "mode must be 0 (forward), 1 (predict_mask) or 2 (predict)");
+        h->m.forward_api(x, x_on_device != 0, B, T, mode, out, out_on_device != 0);
+    });
+}
+
+int vr_stft(vr_handle h, const float* wave, int wave_on_device, int64_t L, float* spec, int spec_on_device) {
+    NEED(h);
+    return guard([&] {
+        VR_CHECK(wave && spec, VR_ERR_BAD_ARGUMENT, "null argument");
+        h->m.stft_api(wave, wave_on_device != 0, L, spec, spec_on_device != 0);
+    });
+}
+
+int vr_istft(vr_handle h, const float* spec, int spec_on_device, int T, float* wave, int wave_on_device) {
+    NEED(h);
+    return guard([&] {
+        VR_CHECK(spec && wave, VR_ERR_BAD_ARGUMENT, "null argument");
+        h->m.istft_api(spec, spec_on_device != 0, T, wave, wave_on_device != 0);
+    });
+}
+
+int vr_separate(vr_handle h, const float* spec, int spec_on_device, int T, int tta, int batchsize, int cropsize,
+                float* y_spec, float* v_spec, int out_on_device) {
+    NEED(h);
+    return guard([&] {
+        VR_CHECK(spec && y_spec && v_spec, VR_ERR_BAD_ARGUMENT, "null argument");
+        VR_CHECK((spec_on_device != 0) == (out_on_device != 0) || true, VR_ERR_BAD_ARGUMENT, "");
+        h->m.separate_api(spec, spec_on_device != 0, T, tta, batchsize, cropsize, y_spec, v_spec, out_on_device != 0);
+    });
+}
+
+int vr_separate_wave(vr_handle h, const float* wave, int wave_on_device, int64_t L, int tta, int batchsize,
+                     int cropsize, float* y_wave, float* v_wave, int out_on_device) {
+    NEED(h);
+    return guard([&] {
+        VR_CHECK(wave && y_wave && v_wave, VR_ERR_BAD_ARGUMENT, "null argument");
+        h->m.separate_wave_api(wave, wave_on_device != 0, L, tta, batchsize, cropsize, y_wave, v_wave, out_on_device != 0);
+    });
+}
+
+int vr_profile_begin(vr_handle h) {
+    NEED(h);
+    return guard([&] { h->m.profile_begin(); });
+}
+
+int vr_profile_end(vr_handle h, double* conv_ms, double* conv_flops, int* conv_launches) {
+    NEED(h);
+    return guard([&] { h->m.profile_end(conv_ms, conv_flops, nullptr, conv_launches); });
+}
+
+int vr_debug_conv2d(vr_handle h, const float* x, int N, int Cin, int H, int W, const float* w, int Cout, int ksize,
+                    int stride, int dil_h, int dil_w, int upsample, const float* affine, float slope, const float* bias,
+                    float* out, float* stats_out) {
+    NEED(h);
+    return guard([&] {
+        VR_CHECK(x && w && out, VR_ERR_BAD_ARGUMENT, "null argument");
+        h->m.debug_conv(x, N, Cin, H, W, w, Cout, ksize, stride, dil_h, dil_w, upsample, affine, slope, bias, out, stats_out);
+    });
+}
+
+int vr_debug_record_taps(vr_handle h, int enable) {
+    NEED(h);
+    return guard([&] { h->m.record_taps = enable != 0; if (!enable) h->m.taps.clear(); });
+}
+
+int64_t vr_debug_get_tap(vr_handle h, const char* name, float* host, int64_t capacity_floats, int64_t* shape4) {
+    if (!h || !name) { g_err = "null argument"; return VR_ERR_BAD_ARGUMENT; }
+    int64_t n = 0;
+    const int rc = guard([&] { n = h->m.get_tap(name, host, capacity_floats, shape4); });
+    return rc == VR_OK ? n : rc;
+}
+
+}  // extern "C"

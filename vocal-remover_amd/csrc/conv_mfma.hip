@@ -1,0 +1,354 @@
+// Fused convolution for the CascadedNet blocks (lib/layers.py:8-64, 67-105) on gfx950.
+//
+// One kernel family covers every conv of the hot path:
+//   3x3 stride 1 (K3), 3x3 stride 2 (K4), 3x3 dilated (K5), 1x1 (K6) -- SURVEY.md section 2.
+// Structure: LDS-staged implicit GEMM.  A workgroup (4 waves) owns MT output channels x a
+// TH x TW tile of output pixels of one image and walks the input channels in chunks of CK:
+//   stage   the haloed input tile  Xs[CK][TH_in][TWp]   (global -> regs -> transform -> LDS)
+//           the weight slice       Ws[KS*KS][CK][MT]
+//   compute for each tap, for each channel pair: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain)
+//           A[i=cout][k=ci pair] from Ws, B[k][j=pixel] from Xs, accumulators stay in registers.
+// The staging step is where the fusion happens (vr_common.h): virtual channel-concat of up to
+// three sources, the decoder's bilinear x2 upsample (align_corners=True), the producer's
+// BatchNorm affine and ReLU/LeakyReLU, and conv zero padding -- so neither the upsampled tensor
+// nor the concatenated tensor nor a normalised copy ever exists in HBM.
+// The epilogue stores the RAW conv output (+ optional bias) and, in training mode, per-block
+// (sum, sumsq) partials per output channel for the BatchNorm batch statistics.
+//
+// fp32 MFMA runs at the fp32 vector rate (157 TFLOP/s peak) but reaches it with one LDS read
+// per operand per 64-cycle instruction, which is what makes a >100 TFLOP/s conv reachable; the
+// VALU stays free for the staging transforms.
+#include "vr_common.h"
+
+namespace vr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float act_apply(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// Fetch one element of source `s` at virtual-input coordinate (hi, wi), channel cl, image n,
+// applying the pending BatchNorm affine + activation (and the bilinear x2 upsample if s.up).
+__device__ __forceinline__ float fetch_src(const ConvSrc& s, int n, int cl, int hi, int wi) {
+    const float* base = s.p + (long long)n * s.sN + (long long)cl * s.sC;
+    if (!s.up) {
+        float raw = base[(long long)hi * s.sH + wi];
+        const float* aff = (hi < s.hsplit) ? s.aff0 : s.aff1;
+        float sc = 1.f, sh = 0.f;
+        if (aff) { sc = aff[2 * cl]; sh = aff[2 * cl + 1]; }
+        float v = act_apply(fmaf(raw, sc, sh), s.slope);
+        if (s.post) v *= s.post[n * s.C + cl];
+        return v;
+    }
+    // torch upsample_bilinear2d, align_corners=True: src = dst * (in-1)/(out-1)
+    float h1r = s.rh * (float)hi;
+    int h1 = (int)h1r;
+    int h1p = (h1 < s.H - 1) ? 1 : 0;
+    float h1l = h1r - (float)h1, h0l = 1.f - h1l;
+    float w1r = s.rw * (float)wi;
+    int w1 = (int)w1r;
+    int w1p = (w1 < s.W - 1) ? 1 : 0;
+    float w1l = w1r - (float)w1, w0l = 1.f - w1l;
+    float sc = 1.f, sh = 0.f;
+    if (s.aff0) { sc = s.aff0[2 * cl]; sh = s.aff0[2 * cl + 1]; }
+    const float* r0 = base + (long long)h1 * s.sH + w1;
+    const float* r1 = r0 + (long long)h1p * s.sH;
+    float v00 = act_apply(fmaf(r0[0], sc, sh), s.slope);
+    float v01 = act_apply(fmaf(r0[w1p], sc, sh), s.slope);
+    float v10 = act_apply(fmaf(r1[0], sc, sh), s.slope);
+    float v11 = act_apply(fmaf(r1[w1p], sc, sh), s.slope);
+    float v = h0l * (w0l * v00 + w1l * v01) + h1l * (w0l * v10 + w1l * v11);
+    if (s.post) v *= s.post[n * s.C + cl];
+    return v;
+}
+
+template <int KS, int S, int DH, int DW, int MT, int TH, int TW, int CK, int WAVES_M>
+struct ConvCfg {
+    static constexpr int KK = KS * KS;
+    static constexpr int WAVES_N = 4 / WAVES_M;
+    static constexpr int NG = TH * TW / 32;
+    static constexpr int WM = MT / 32 / WAVES_M;
+    static constexpr int WN = NG / WAVES_N;
+    static constexpr int TH_in = (TH - 1) * S + (KS - 1) * DH + 1;
+    static constexpr int TW_in = (TW - 1) * S + (KS - 1) * DW + 1;
+    // Row pitch in LDS.  TW=32: one row per 32-lane group -> any pitch is conflict-free.
+    // TW=16: two rows per 32-lane group -> pitch == 16 (mod 32) keeps the two 16-lane runs on
+    // disjoint banks (stride-1 case).
+    static constexpr int TWp = (TW == 16) ? ((TW_in + 15) / 32 * 32 + 16) : ((TW_in + 1) & ~1);
+    static constexpr int XS = CK * TH_in * TWp;
+    static constexpr int WS = KK * CK * MT;
+    static constexpr int LDS_BYTES = (XS + WS) * 4;
+    static_assert(WM >= 1 && WN >= 1 && WM * WAVES_M * 32 == MT && WN * WAVES_N == NG, "tile split");
+    static_assert(XS % 4 == 0, "weight slab must stay 16B aligned");
+    static_assert(TWp >= TW_in, "pitch");
+};
+
+template <int KS, int S, int DH, int DW, int MT, int TH, int TW, int CK, int WAVES_M>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+    using Cfg = ConvCfg<KS, S, DH, DW, MT, TH, TW, CK, WAVES_M>;
+    constexpr int KK = Cfg::KK, WM = Cfg::WM, WN = Cfg::WN, WAVES_N = Cfg::WAVES_N;
+    constexpr int TH_in = Cfg::TH_in, TW_in = Cfg::TW_in, TWp = Cfg::TWp;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;
+    float* Ws = smem + Cfg::XS;
+
+    // ---- block -> (pixel tile, cout tile).  Blocks land on XCD (id % 8): keep all cout tiles
+    // of one pixel tile on the same XCD, back to back, so the input tile is fetched into that
+    // XCD's L2 once (placement is a speed assumption only).
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int rr = id >> 3;
+    const int ct = rr % a.nct;
+    const int pt = (rr / a.nct) * 8 + xcd;
+    if (pt >= a.npt) return;
+    const int tiles_per_img = a.tiles_h * a.tiles_w;
+    const int n = pt / tiles_per_img;
+    const int trem = pt - n * tiles_per_img;
+    const int h0 = (trem / a.tiles_w) * TH;
+    const int w0 = (trem % a.tiles_w) * TW;
+    const int co0 = ct * MT;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int khalf = lane >> 5;
+    const int l31 = lane & 31;
+
+    // per-lane B-operand base offsets (pixel of each owned group) inside one channel-pair slab
+    int boff[WN];
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) {
+        const int pix = (wn * WN + ni) * 32 + l31;
+        const int r = pix / TW, c = pix % TW;
+        boff[ni] = (khalf * TH_in + r * S) * TWp + c * S;
+    }
+    const int aoff = khalf * MT + wm * WM * 32 + l31;
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int hbase = h0 * S - a.pad_h;
+    const int wbase = w0 * S - a.pad_w;
+
+    for (int c0 = 0; c0 < a.Cin; c0 += CK) {
+        __syncthreads();   // previous chunk's MFMA reads are done
+        // ---------------- stage weights: Ws[tap][cl][m] <- w[(c0+cl)][tap][co0+m] -------------
+        {
+            constexpr int M4 = MT / 4;
+            for (int idx = tid; idx < CK * KK * M4; idx += 256) {
+                const int m4 = idx % M4;
+                const int t2 = idx / M4;
+                const int tap = t2 % KK;
+                const int cl = t2 / KK;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c0 + cl < a.Cin)
+                    v = *reinterpret_cast<const float4*>(
+                        a.w + ((long long)(c0 + cl) * KK + tap) * a.CoutPad + co0 + m4 * 4);
+                *reinterpret_cast<float4*>(Ws + (tap * CK + cl) * MT + m4 * 4) = v;
+            }
+        }
+        // ---------------- stage input: one channel per wave pass, lanes over the haloed tile ----
+        for (int cl = wave; cl < CK; cl += 4) {
+            const int ci = c0 + cl;               // wave-uniform
+            float* dst = Xs + cl * TH_in * TWp;
+            if (ci >= a.Cin) {
+                for (int e = lane; e < TH_in * TW_in; e += 64) dst[(e / TW_in) * TWp + (e % TW_in)] = 0.f;
+                continue;
+            }
+            const int si = (ci >= a.c1) + (ci >= a.c2);
+            const ConvSrc& s = a.src[si];
+            const int clc = ci - (si == 0 ? 0 : (si == 1 ? a.c1 : a.c2));
+            for (int e = lane; e < TH_in * TW_in; e += 64) {
+                const int hh = e / TW_in, ww = e % TW_in;
+                const int hi = hbase + hh, wi = wbase + ww;
+                float v = 0.f;
+                if (hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win) v = fetch_src(s, n, clc, hi, wi);
+                dst[hh * TWp + ww] = v;
+            }
+        }
+        __syncthreads();
+        // ---------------- MFMA over this chunk ---------------------------------------------------
+        const int cleft = a.Cin - c0;
+        const int npair = ((cleft < CK ? cleft : CK) + 1) >> 1;
+#pragma unroll
+        for (int tap = 0; tap < KK; ++tap) {
+            const int kh = tap / KS, kw = tap % KS;
+            const int toff = kh * DH * TWp + kw * DW;
+            for (int kk = 0; kk < npair; ++kk) {
+                float av[WM], bv[WN];
+#pragma unroll
+                for (int mi = 0; mi < WM; ++mi) av[mi] = Ws[(tap * CK + 2 * kk) * MT + aoff + mi * 32];
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni) bv[ni] = Xs[2 * kk * TH_in * TWp + toff + boff[ni]];
+#pragma unroll
+                for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---------------- epilogue: raw store (+bias) --------------------------------------------------
+    // C/D layout of 32x32 MFMA: col (pixel) = lane & 31, row (cout) = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + (wm * WM + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            const float b = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni) {
+                const int pix = (wn * WN + ni) * 32 + l31;
+                const int ho = h0 + pix / TW, wo = w0 + pix % TW;
+                const float v = acc[mi][ni][r] + b;
+                acc[mi][ni][r] = v;
+                if (co < a.Cout && ho < a.Hout && wo < a.Wout)
+                    a.out[(long long)n * a.oN + (long long)co * a.oC + (long long)ho * a.oH + wo] = v;
+            }
+        }
+    }
+
+    // ---------------- BatchNorm partial statistics (training) -----------------------------------------
+    if (a.part) {
+        __syncthreads();                       // all waves finished reading Xs/Ws
+        float* red = smem;                     // [WAVES_N][MT][2]
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni) {
+                    const int pix = (wn * WN + ni) * 32 + l31;
+                    const int ho = h0 + pix / TW, wo = w0 + pix % TW;
+                    if (ho < a.Hout && wo < a.Wout) {
+                        const float v = acc[mi][ni][r];
+                        s1 += v;
+                        s2 = fmaf(v, v, s2);
+                    }
+                }
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) {   // stays inside each 32-lane half
+                    s1 += __shfl_xor(s1, off, 64);
+                    s2 += __shfl_xor(s2, off, 64);
+                }
+                if (l31 == 0) {
+                    const int m = (wm * WM + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    red[(wn * MT + m) * 2 + 0] = s1;
+                    red[(wn * MT + m) * 2 + 1] = s2;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < MT) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES_N; ++w) {
+                s1 += red[(w * MT + tid) * 2 + 0];
+                s2 += red[(w * MT + tid) * 2 + 1];
+            }
+            const int co = co0 + tid;
+            if (co < a.Cout) {
+                a.part[((long long)pt * a.Cout + co) * 2 + 0] = s1;
+                a.part[((long long)pt * a.Cout + co) * 2 + 1] = s2;
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Launcher: pick the instantiation from the layer shape.
+// -------------------------------------------------------------------------------------------------
+struct TileChoice { int MT, TH, TW; };
+
+static TileChoice pick_tile(const ConvArgs& a, const ConvShape& s) {
+    TileChoice t;
+    const bool dilated = (s.dil_h != 1 || s.dil_w != 1);
+    t.TW = (a.Wout >= 32 && !dilated) ? 32 : 16;
+    t.TH = (t.TW == 32) ? 8 : 16;
+    t.MT = (a.CoutPad % 64 == 0) ? 64 : 32;
+    if (t.MT == 64) {
+        // small grids: halve the cout tile to double the number of workgroups
+        long long tiles = (long long)a.N * ((a.Hout + t.TH - 1) / t.TH) * ((a.Wout + t.TW - 1) / t.TW);
+        if (tiles * (a.CoutPad / 64) < 512) t.MT = 32;
+    }
+    return t;
+}
+
+void conv_fill_tiling(ConvArgs& a, const ConvShape& s) {
+    TileChoice t = pick_tile(a, s);
+    a.tiles_w = (a.Wout + t.TW - 1) / t.TW;
+    a.tiles_h = (a.Hout + t.TH - 1) / t.TH;
+    a.npt = a.N * a.tiles_h * a.tiles_w;
+    a.nct = a.CoutPad / t.MT;
+}
+
+size_t conv_part_count(const ConvArgs& a, const ConvShape& s) {
+    ConvArgs b = a;
+    conv_fill_tiling(b, s);
+    return (size_t)b.npt;
+}
+
+template <int KS, int S, int DH, int DW, int MT, int TH, int TW, int CK, int WAVES_M>
+static void launch_inst(const ConvArgs& a, hipStream_t st) {
+    using Cfg = ConvCfg<KS, S, DH, DW, MT, TH, TW, CK, WAVES_M>;
+    auto kern = conv_mfma_kernel<KS, S, DH, DW, MT, TH, TW, CK, WAVES_M>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+        attr_set = true;
+    }
+    const int groups = (a.npt + 7) / 8;
+    const int grid = groups * 8 * a.nct;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::LDS_BYTES, st, a);
+    VR_HIP(hipGetLastError());
+}
+
+template <int KS, int S, int DH, int DW, int CK>
+static void launch_by_tile(const ConvArgs& a, const TileChoice& t, hipStream_t st) {
+    if (t.TW == 32) {
+        if constexpr (DH == 1 && DW == 1) {
+            if (t.MT == 64) launch_inst<KS, S, DH, DW, 64, 8, 32, CK, 1>(a, st);
+            else            launch_inst<KS, S, DH, DW, 32, 8, 32, CK, 1>(a, st);
+        } else {
+            throw Error(-2, "dilated conv uses TW=16 tiles only");
+        }
+    } else {
+        if (t.MT == 64) launch_inst<KS, S, DH, DW, 64, 16, 16, CK, 1>(a, st);
+        else            launch_inst<KS, S, DH, DW, 32, 16, 16, CK, 1>(a, st);
+    }
+}
+
+double launch_conv(const ConvArgs& a_in, const ConvShape& s, hipStream_t st) {
+    ConvArgs a = a_in;
+    conv_fill_tiling(a, s);
+    TileChoice t = pick_tile(a, s);
+    VR_CHECK(a.CoutPad % t.MT == 0 && a.CoutPad % 32 == 0, -2, "CoutPad must be a multiple of the cout tile");
+    VR_CHECK(a.nsrc >= 1 && a.nsrc <= 3, -2, "conv takes 1..3 sources");
+    if (s.KS == 1) {
+        VR_CHECK(s.stride == 1 && s.dil_h == 1 && s.dil_w == 1, -2, "1x1 conv: stride/dilation must be 1");
+        launch_by_tile<1, 1, 1, 1, 32>(a, t, st);
+    } else if (s.KS == 3 && s.stride == 1 && s.dil_h == 1 && s.dil_w == 1) {
+        launch_by_tile<3, 1, 1, 1, 8>(a, t, st);
+    } else if (s.KS == 3 && s.stride == 2 && s.dil_h == 1 && s.dil_w == 1) {
+        launch_by_tile<3, 2, 1, 1, 4>(a, t, st);
+    } else if (s.KS == 3 && s.stride == 1 && s.dil_h == 4 && s.dil_w == 2) {
+        launch_by_tile<3, 1, 4, 2, 4>(a, t, st);
+    } else if (s.KS == 3 && s.stride == 1 && s.dil_h == 8 && s.dil_w == 4) {
+        launch_by_tile<3, 1, 8, 4, 4>(a, t, st);
+    } else if (s.KS == 3 && s.stride == 1 && s.dil_h == 12 && s.dil_w == 6) {
+        launch_by_tile<3, 1, 12, 6, 4>(a, t, st);
+    } else {
+        throw Error(-2, "unsupported conv shape (kernel/stride/dilation)");
+    }
+    return 2.0 * a.N * (double)a.Hout * a.Wout * (double)a.Cout * a.Cin * s.KS * s.KS;
+}
+
+}  // namespace vr

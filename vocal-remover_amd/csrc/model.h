@@ -1,0 +1,178 @@
+// Host-side model: parameter registry (reference state_dict keys), network topology of
+// lib/nets.py / lib/layers.py, forward executor, and the device-resident Separator pipeline.
+#pragma once
+#include <deque>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace vr {
+
+// Bump allocator over one device slab; `dry` mode only measures.
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, off = 0, peak = 0;
+    bool dry = false;
+    void* alloc(size_t bytes) {
+        const size_t a = (off + 255) & ~size_t(255);
+        off = a + bytes;
+        if (off > peak) peak = off;
+        if (dry) return reinterpret_cast<void*>(uintptr_t(256));   // non-null dummy, never dereferenced
+        if (off > cap) throw Error(-4, "workspace arena overflow (planning bug)");
+        return base + a;
+    }
+    float* allocf(size_t n) { return static_cast<float*>(alloc(n * sizeof(float))); }
+    void reset() { off = 0; }
+};
+
+enum ParamKind { PK_PLAIN = 0, PK_CONV = 1, PK_LSTM_IH = 2, PK_BUFFER = 3, PK_NBT = 4 };
+
+struct Param {
+    std::string key;
+    std::vector<int64_t> shape;     // torch shape
+    ParamKind kind = PK_PLAIN;
+    size_t numel = 0;               // torch numel
+    size_t dev_numel = 0;           // device footprint (floats) incl. padding
+    size_t off = 0;                 // offset (floats) into its arena
+    bool trainable = true;
+    // PK_CONV / PK_LSTM_IH layout info: device layout [Cin][KK][CoutPad]
+    int Cout = 0, Cin = 0, KK = 1, CoutPad = 0, co_off = 0;
+    Param* alias_of = nullptr;      // PK_LSTM_IH reverse half lives inside the forward half's buffer
+    float* dev = nullptr;
+    int64_t nbt = 0;                // PK_NBT value (host)
+};
+
+struct BN {
+    int C = 0;
+    Param *w = nullptr, *b = nullptr, *rm = nullptr, *rv = nullptr, *nbt = nullptr;
+    float* affine = nullptr;        // [rows][2] scale, shift (device)
+    int bcast = 0;                  // >0: C==1, affine replicated to this many rows
+    float* save_mean = nullptr;
+    float* save_invstd = nullptr;
+};
+
+struct Conv {
+    std::string name;
+    int Cin = 0, Cout = 0, CoutPad = 0, KS = 3, stride = 1, dh = 1, dw = 1, pad_h = 1, pad_w = 1;
+    Param* w = nullptr;
+    BN* bn = nullptr;
+    float slope = 0.f;              // activation after the BatchNorm
+};
+
+struct LSTMMod {
+    Conv squeeze;                   // 1x1 conv 2c -> 1 (+BN+ReLU), run by the thin-conv kernel
+    int nin = 0, hid = 0;           // LSTM input size (= nbins at dec2 level), hidden per direction
+    Conv proj;                      // W_ih of both directions as one 1x1 conv (nin -> 8*hid), no BN
+    Param *b_ih_f = nullptr, *b_hh_f = nullptr, *b_ih_r = nullptr, *b_hh_r = nullptr;   // [4H] each
+    Param *whh_f = nullptr, *whh_r = nullptr;
+    Conv dense;                     // Linear(2*hid -> nin) as 1x1 conv + BatchNorm1d + ReLU
+    Param* dense_b = nullptr;
+};
+
+struct BaseNetL {
+    std::string prefix;
+    int c = 0;
+    Conv enc1;
+    Conv enc_a[4], enc_b[4];        // enc2..enc5: conv1 (stride 2), conv2
+    Conv aspp_pool, aspp_c2, aspp_d[3], aspp_bott;
+    float* aspp_aff = nullptr;      // [4*8c][2]: affine tables of conv2..conv5 laid out contiguously
+    Conv dec[4];                    // dec4, dec3, dec2, dec1
+    LSTMMod lstm;
+};
+
+struct ProfileEntry { hipEvent_t e0, e1; double flops; int kind; };
+
+class Model {
+public:
+    Model(int device, int n_fft, int hop, int nout, int nout_lstm);
+    ~Model();
+
+    int device, n_fft, hop, nout, nout_lstm, max_bin, output_bin, offset = 64;
+
+    // ---- parameters ----
+    std::deque<Param> params;
+    std::map<std::string, Param*> by_key;
+    void set_param(const std::string& key, const void* host, const int64_t* shape, int ndim);
+    void get_param(const std::string& key, void* host, int64_t cap_bytes);
+    void set_training(bool t);
+    bool training = false;
+
+    // ---- forward over host or device input ----
+    // x: [B,2,output_bin,T] fp32 magnitudes.  mode 0: forward (full width), 1: predict_mask
+    // (offset crop), 2: predict (x*mask, offset crop).  out sized accordingly.
+    void forward_api(const float* x, bool x_on_device, int B, int T, int mode, float* out, bool out_on_device);
+
+    // ---- signal path ----
+    void stft_api(const float* wave, bool on_dev, long long L, float* spec, bool spec_on_dev);
+    void istft_api(const float* spec, bool on_dev, int T, float* wave, bool wave_on_dev);
+    // spec [2,bins,T] complex64 -> y_spec, v_spec (same shape)
+    void separate_api(const float* spec, bool on_dev, int T, int tta, int batchsize, int cropsize,
+                      float* y_spec, float* v_spec, bool out_on_dev);
+    // wave [2,L] -> y_wave, v_wave [2, hop*(T-1)]: whole inference.py pipeline, device resident
+    void separate_wave_api(const float* wave, bool on_dev, long long L, int tta, int batchsize, int cropsize,
+                           float* y_wave, float* v_wave, bool out_on_dev);
+
+    // ---- debug / test hooks ----
+    void debug_conv(const float* x, int N, int Cin, int H, int W, const float* w_oihw, int Cout, int KS, int stride,
+                    int dh, int dw, int up, const float* aff, float slope, const float* bias, float* out,
+                    float* stats_out);
+    bool record_taps = false;
+    std::map<std::string, Tensor> taps;
+    int64_t get_tap(const std::string& name, float* host, int64_t cap_floats, int64_t* shape4);
+
+    // ---- profiling ----
+    bool profiling = false;
+    std::vector<ProfileEntry> prof;
+    void profile_begin();
+    void profile_end(double* conv_ms, double* conv_flops, double* other_ms, int* launches);
+
+    hipStream_t stream = nullptr;
+
+private:
+    // arenas
+    float* p_arena = nullptr; size_t p_floats = 0;      // trainable parameters (kernel layouts)
+    float* b_arena = nullptr; size_t b_floats = 0;      // buffers (running stats), affine tables, saves
+    Arena ws;                                            // activations workspace
+    Arena io;                                            // persistent I/O staging (spec, mask, waves)
+    void ensure_ws(size_t bytes);
+    void ensure_io(size_t bytes);
+
+    std::deque<BN> bns;
+    std::vector<BN*> bn_list;
+    BNFoldDesc* d_fold = nullptr;
+    bool affine_dirty = true;
+    void fold_eval_affines();
+
+    BaseNetL nets_[5];
+    Conv tail1, tail2;                                   // stg{1,2}_low_band_net.1
+    Param *out_w = nullptr, *aux_out_w = nullptr;
+
+    FFTPlan plan{};
+
+    // builders
+    Param* add_param(const std::string& key, std::vector<int64_t> shape, ParamKind kind, bool trainable);
+    BN* add_bn(const std::string& prefix, int C, int bcast);
+    void build_cba(Conv& L, const std::string& prefix, int nin, int nout_, int ks, int stride, int pad_h, int pad_w,
+                   int dh, int dw, float slope);
+    void build_basenet(BaseNetL& B, const std::string& prefix, int nin, int c, int nin_lstm, int nout_lstm_);
+    void finalize_layout();
+
+    // executor
+    struct SrcSpec { Tensor t; bool up = false; int bcastH = 0; };
+    Tensor run_conv(Conv& L, const std::vector<SrcSpec>& srcs, int N, const Tensor* out_view, const float* bias,
+                    bool batch_as_h);
+    Tensor run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, const Tensor* out_view);
+    Tensor run_lstm(LSTMMod& M, const Tensor& h);
+    Tensor run_net(const Tensor& x);                     // -> stg3 dec1 output (raw + affine)
+    void tap(const std::string& name, const Tensor& t);
+    bool dry = false;
+    const float* dropout_dev = nullptr;                  // [5][N][Cmax] keep-masks (training), or null
+    void plan_and_reserve(int B, int T, size_t extra_bytes);
+    void record_begin(int kind, double flops);
+    void record_end();
+};
+
+}  // namespace vr

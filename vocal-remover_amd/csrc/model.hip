@@ -1,0 +1,898 @@
+// Host side of libvr_mi355.so: see model.h.  Topology follows lib/nets.py:8-141 and
+// lib/layers.py:8-133 of the reference; parameter keys are the reference's state_dict keys.
+#include "model.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace vr {
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// =====================================================================================================
+// construction
+// =====================================================================================================
+Param* Model::add_param(const std::string& key, std::vector<int64_t> shape, ParamKind kind, bool trainable) {
+    params.emplace_back();
+    Param* p = &params.back();
+    p->key = key;
+    p->shape = std::move(shape);
+    p->kind = kind;
+    p->trainable = trainable;
+    p->numel = 1;
+    for (auto d : p->shape) p->numel *= (size_t)d;
+    p->dev_numel = p->numel;
+    if (kind == PK_CONV) {
+        p->Cout = (int)p->shape[0];
+        p->Cin = (int)p->shape[1];
+        p->KK = p->shape.size() == 4 ? (int)(p->shape[2] * p->shape[3]) : 1;
+        p->CoutPad = round_up(p->Cout, 32);
+        p->dev_numel = (size_t)p->Cin * p->KK * p->CoutPad;
+    }
+    if (kind == PK_NBT) p->dev_numel = 0;
+    by_key[key] = p;
+    return p;
+}
+
+BN* Model::add_bn(const std::string& prefix, int C, int bcast) {
+    bns.emplace_back();
+    BN* b = &bns.back();
+    b->C = C;
+    b->bcast = bcast;
+    b->w = add_param(prefix + ".weight", {C}, PK_PLAIN, true);
+    b->b = add_param(prefix + ".bias", {C}, PK_PLAIN, true);
+    b->rm = add_param(prefix + ".running_mean", {C}, PK_BUFFER, false);
+    b->rv = add_param(prefix + ".running_var", {C}, PK_BUFFER, false);
+    b->nbt = add_param(prefix + ".num_batches_tracked", {}, PK_NBT, false);
+    bn_list.push_back(b);
+    return b;
+}
+
+// layers.Conv2DBNActiv (lib/layers.py:8-26)
+void Model::build_cba(Conv& L, const std::string& prefix, int nin, int nout_, int ks, int stride, int pad_h, int pad_w,
+                      int dh, int dw, float slope) {
+    L.name = prefix;
+    L.Cin = nin; L.Cout = nout_; L.CoutPad = round_up(nout_, 32);
+    L.KS = ks; L.stride = stride; L.pad_h = pad_h; L.pad_w = pad_w; L.dh = dh; L.dw = dw; L.slope = slope;
+    L.w = add_param(prefix + ".conv.0.weight", {nout_, nin, ks, ks}, PK_CONV, true);
+    L.bn = add_bn(prefix + ".conv.1", nout_, 0);
+}
+
+// nets.BaseNet (lib/nets.py:10-24)
+void Model::build_basenet(BaseNetL& B, const std::string& p, int nin, int c, int nin_lstm, int nout_lstm_) {
+    B.prefix = p; B.c = c;
+    const float RELU = 0.f, LEAKY = 0.01f;
+    build_cba(B.enc1, p + ".enc1", nin, c, 3, 1, 1, 1, 1, 1, RELU);
+    const int ch[5] = {c, 2 * c, 4 * c, 6 * c, 8 * c};
+    for (int i = 0; i < 4; ++i) {
+        const std::string e = p + ".enc" + std::to_string(i + 2);
+        build_cba(B.enc_a[i], e + ".conv1", ch[i], ch[i + 1], 3, 2, 1, 1, 1, 1, LEAKY);
+        build_cba(B.enc_b[i], e + ".conv2", ch[i + 1], ch[i + 1], 3, 1, 1, 1, 1, 1, LEAKY);
+    }
+    const int C8 = 8 * c;
+    build_cba(B.aspp_pool, p + ".aspp.conv1.1", C8, C8, 1, 1, 0, 0, 1, 1, RELU);
+    build_cba(B.aspp_c2, p + ".aspp.conv2", C8, C8, 1, 1, 0, 0, 1, 1, RELU);
+    const int dil[3][2] = {{4, 2}, {8, 4}, {12, 6}};
+    for (int i = 0; i < 3; ++i)
+        build_cba(B.aspp_d[i], p + ".aspp.conv" + std::to_string(i + 3), C8, C8, 3, 1, dil[i][0], dil[i][1], dil[i][0],
+                  dil[i][1], RELU);
+    build_cba(B.aspp_bott, p + ".aspp.bottleneck", 5 * C8, C8, 1, 1, 0, 0, 1, 1, RELU);
+    build_cba(B.dec[0], p + ".dec4.conv1", 14 * c, 6 * c, 3, 1, 1, 1, 1, 1, RELU);
+    build_cba(B.dec[1], p + ".dec3.conv1", 10 * c, 4 * c, 3, 1, 1, 1, 1, 1, RELU);
+    build_cba(B.dec[2], p + ".dec2.conv1", 6 * c, 2 * c, 3, 1, 1, 1, 1, 1, RELU);
+    // layers.LSTMModule (lib/layers.py:110-122)
+    LSTMMod& M = B.lstm;
+    const std::string q = p + ".lstm_dec2";
+    const int hid = nout_lstm_ / 2;
+    M.nin = nin_lstm; M.hid = hid;
+    M.squeeze.name = q + ".conv";
+    M.squeeze.Cin = 2 * c; M.squeeze.Cout = 1; M.squeeze.KS = 1; M.squeeze.slope = RELU;
+    M.squeeze.w = add_param(q + ".conv.conv.0.weight", {1, 2 * c, 1, 1}, PK_PLAIN, true);
+    M.squeeze.bn = add_bn(q + ".conv.conv.1", 1, nin_lstm);
+    M.proj.name = q + ".lstm";
+    M.proj.Cin = nin_lstm; M.proj.Cout = 8 * hid; M.proj.CoutPad = round_up(8 * hid, 32);
+    M.proj.KS = 1; M.proj.stride = 1; M.proj.pad_h = M.proj.pad_w = 0; M.proj.bn = nullptr; M.proj.slope = 1.f;
+    Param* ihf = add_param(q + ".lstm.weight_ih_l0", {4 * hid, nin_lstm}, PK_LSTM_IH, true);
+    M.whh_f = add_param(q + ".lstm.weight_hh_l0", {4 * hid, hid}, PK_PLAIN, true);
+    M.b_ih_f = add_param(q + ".lstm.bias_ih_l0", {4 * hid}, PK_PLAIN, true);
+    M.b_hh_f = add_param(q + ".lstm.bias_hh_l0", {4 * hid}, PK_PLAIN, true);
+    Param* ihr = add_param(q + ".lstm.weight_ih_l0_reverse", {4 * hid, nin_lstm}, PK_LSTM_IH, true);
+    M.whh_r = add_param(q + ".lstm.weight_hh_l0_reverse", {4 * hid, hid}, PK_PLAIN, true);
+    M.b_ih_r = add_param(q + ".lstm.bias_ih_l0_reverse", {4 * hid}, PK_PLAIN, true);
+    M.b_hh_r = add_param(q + ".lstm.bias_hh_l0_reverse", {4 * hid}, PK_PLAIN, true);
+    ihf->Cout = 4 * hid; ihf->Cin = nin_lstm; ihf->KK = 1; ihf->CoutPad = M.proj.CoutPad; ihf->co_off = 0;
+    ihf->dev_numel = (size_t)nin_lstm * M.proj.CoutPad;
+    ihr->Cout = 4 * hid; ihr->Cin = nin_lstm; ihr->KK = 1; ihr->CoutPad = M.proj.CoutPad; ihr->co_off = 4 * hid;
+    ihr->dev_numel = 0; ihr->alias_of = ihf;
+    M.proj.w = ihf;
+    M.dense.name = q + ".dense";
+    M.dense.Cin = 2 * hid; M.dense.Cout = nin_lstm; M.dense.CoutPad = round_up(nin_lstm, 32);
+    M.dense.KS = 1; M.dense.stride = 1; M.dense.pad_h = M.dense.pad_w = 0; M.dense.slope = 0.f;
+    M.dense.w = add_param(q + ".dense.0.weight", {nin_lstm, 2 * hid}, PK_CONV, true);
+    M.dense_b = add_param(q + ".dense.0.bias", {nin_lstm}, PK_PLAIN, true);
+    M.dense.bn = add_bn(q + ".dense.1", nin_lstm, 0);
+    build_cba(B.dec[3], p + ".dec1.conv1", 3 * c + 1, c, 3, 1, 1, 1, 1, 1, RELU);
+}
+
+Model::Model(int device_, int n_fft_, int hop_, int nout_, int nout_lstm_)
+    : device(device_), n_fft(n_fft_), hop(hop_), nout(nout_), nout_lstm(nout_lstm_) {
+    VR_CHECK(n_fft >= 64 && (n_fft & (n_fft - 1)) == 0 && n_fft <= 8192, -2, "n_fft must be a power of two in [64, 8192]");
+    VR_CHECK(hop > 0, -2, "hop_length must be positive");
+    VR_CHECK(nout % 4 == 0 && nout >= 4 && nout_lstm % 4 == 0 && nout_lstm >= 4, -2, "nout / nout_lstm must be multiples of 4");
+    max_bin = n_fft / 2;
+    output_bin = n_fft / 2 + 1;
+    VR_CHECK((max_bin / 2) % 16 == 0, -2, "n_fft/4 must be a multiple of 16 (four stride-2 encoders)");
+    VR_HIP(hipSetDevice(device));
+    VR_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    const int nin = 2;
+    const int nin_lstm = max_bin / 2;
+    // lib/nets.py:59-80
+    build_basenet(nets_[0], "stg1_low_band_net.0", nin, nout / 2, nin_lstm / 2, nout_lstm);
+    build_cba(tail1, "stg1_low_band_net.1", nout / 2, nout / 4, 1, 1, 0, 0, 1, 1, 0.f);
+    build_basenet(nets_[1], "stg1_high_band_net", nin, nout / 4, nin_lstm / 2, nout_lstm / 2);
+    build_basenet(nets_[2], "stg2_low_band_net.0", nout / 4 + nin, nout, nin_lstm / 2, nout_lstm);
+    build_cba(tail2, "stg2_low_band_net.1", nout, nout / 2, 1, 1, 0, 0, 1, 1, 0.f);
+    build_basenet(nets_[3], "stg2_high_band_net", nout / 4 + nin, nout / 2, nin_lstm / 2, nout_lstm / 2);
+    build_basenet(nets_[4], "stg3_full_band_net", 3 * nout / 4 + nin, nout, nin_lstm, nout_lstm);
+    out_w = add_param("out.weight", {nin, nout, 1, 1}, PK_PLAIN, true);
+    aux_out_w = add_param("aux_out.weight", {nin, 3 * nout / 4, 1, 1}, PK_PLAIN, true);   // never used (nets.py:80)
+    finalize_layout();
+
+    // FFT plan: twiddles and periodic Hann window computed in double on the host
+    plan.n_fft = n_fft;
+    plan.log2n = 0;
+    while ((1 << plan.log2n) < n_fft) ++plan.log2n;
+    std::vector<float2> tw(n_fft / 2);
+    std::vector<float> win(n_fft);
+    const double PI = 3.14159265358979323846;
+    for (int k = 0; k < n_fft / 2; ++k) {
+        const double a = -2.0 * PI * k / n_fft;
+        tw[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    for (int i = 0; i < n_fft; ++i) win[i] = (float)(0.5 - 0.5 * std::cos(2.0 * PI * i / n_fft));
+    VR_HIP(hipMalloc(&plan.twiddle, tw.size() * sizeof(float2)));
+    VR_HIP(hipMalloc(&plan.window, win.size() * sizeof(float)));
+    VR_HIP(hipMemcpy(plan.twiddle, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
+    VR_HIP(hipMemcpy(plan.window, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
+}
+
+void Model::finalize_layout() {
+    size_t poff = 0, boff = 0;
+    auto bump = [](size_t& o, size_t n) { size_t a = (o + 63) & ~size_t(63); o = a + n; return a; };
+    for (auto& p : params) {
+        if (p.kind == PK_NBT || p.alias_of) continue;
+        if (p.trainable) p.off = bump(poff, p.dev_numel);
+        else p.off = bump(boff, p.dev_numel);
+    }
+    // BatchNorm affine tables + saved batch statistics live in the buffer arena
+    std::vector<size_t> aff_off(bn_list.size()), sm_off(bn_list.size()), si_off(bn_list.size());
+    for (size_t i = 0; i < bn_list.size(); ++i) {
+        BN* b = bn_list[i];
+        const int rows = b->bcast ? b->bcast : b->C;
+        aff_off[i] = bump(boff, (size_t)rows * 2);
+        sm_off[i] = bump(boff, (size_t)b->C);
+        si_off[i] = bump(boff, (size_t)b->C);
+    }
+    size_t aspp_off[5];
+    for (int i = 0; i < 5; ++i) aspp_off[i] = bump(boff, (size_t)4 * 8 * nets_[i].c * 2);
+    p_floats = poff + 64; b_floats = boff + 64;
+    VR_HIP(hipMalloc(&p_arena, p_floats * sizeof(float)));
+    VR_HIP(hipMalloc(&b_arena, b_floats * sizeof(float)));
+    VR_HIP(hipMemset(p_arena, 0, p_floats * sizeof(float)));
+    VR_HIP(hipMemset(b_arena, 0, b_floats * sizeof(float)));
+    for (auto& p : params) {
+        if (p.kind == PK_NBT || p.alias_of) continue;
+        p.dev = (p.trainable ? p_arena : b_arena) + p.off;
+    }
+    for (auto& p : params)
+        if (p.alias_of) p.dev = p.alias_of->dev;
+    for (size_t i = 0; i < bn_list.size(); ++i) {
+        bn_list[i]->affine = b_arena + aff_off[i];
+        bn_list[i]->save_mean = b_arena + sm_off[i];
+        bn_list[i]->save_invstd = b_arena + si_off[i];
+    }
+    for (int i = 0; i < 5; ++i) {
+        BaseNetL& B = nets_[i];
+        B.aspp_aff = b_arena + aspp_off[i];
+        const size_t blk = (size_t)8 * B.c * 2;
+        B.aspp_c2.bn->affine = B.aspp_aff;
+        for (int j = 0; j < 3; ++j) B.aspp_d[j].bn->affine = B.aspp_aff + (j + 1) * blk;
+    }
+    // default BatchNorm state = torch's fresh module: weight 1, running_var 1
+    for (BN* b : bn_list) {
+        std::vector<float> ones(b->C, 1.f);
+        VR_HIP(hipMemcpy(b->w->dev, ones.data(), b->C * sizeof(float), hipMemcpyHostToDevice));
+        VR_HIP(hipMemcpy(b->rv->dev, ones.data(), b->C * sizeof(float), hipMemcpyHostToDevice));
+    }
+    std::vector<BNFoldDesc> descs;
+    for (BN* b : bn_list) descs.push_back(BNFoldDesc{b->w->dev, b->b->dev, b->rm->dev, b->rv->dev, b->affine, b->C, b->bcast});
+    VR_HIP(hipMalloc(&d_fold, descs.size() * sizeof(BNFoldDesc)));
+    VR_HIP(hipMemcpy(d_fold, descs.data(), descs.size() * sizeof(BNFoldDesc), hipMemcpyHostToDevice));
+    affine_dirty = true;
+}
+
+Model::~Model() {
+    hipSetDevice(device);
+    if (stream) hipStreamSynchronize(stream);
+    hipFree(p_arena); hipFree(b_arena); hipFree(d_fold);
+    hipFree(ws.base); hipFree(io.base);
+    hipFree(plan.twiddle); hipFree(plan.window);
+    if (stream) hipStreamDestroy(stream);
+}
+
+// =====================================================================================================
+// parameters
+// =====================================================================================================
+void Model::set_param(const std::string& key, const void* host, const int64_t* shape, int ndim) {
+    auto it = by_key.find(key);
+    VR_CHECK(it != by_key.end(), -2, "unknown parameter key: " + key);
+    Param& p = *it->second;
+    VR_CHECK((size_t)ndim == p.shape.size(), -2, "shape rank mismatch for " + key);
+    for (int i = 0; i < ndim; ++i) VR_CHECK(shape[i] == p.shape[i], -2, "shape mismatch for " + key);
+    VR_HIP(hipSetDevice(device));
+    VR_HIP(hipStreamSynchronize(stream));
+    if (p.kind == PK_NBT) { p.nbt = *static_cast<const int64_t*>(host); return; }
+    const float* src = static_cast<const float*>(host);
+    if (p.kind == PK_CONV) {
+        std::vector<float> tmp((size_t)p.Cin * p.KK * p.CoutPad, 0.f);
+        for (int co = 0; co < p.Cout; ++co)
+            for (int ci = 0; ci < p.Cin; ++ci)
+                for (int k = 0; k < p.KK; ++k)
+                    tmp[((size_t)ci * p.KK + k) * p.CoutPad + co] = src[((size_t)co * p.Cin + ci) * p.KK + k];
+        VR_HIP(hipMemcpy(p.dev, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice));
+    } else if (p.kind == PK_LSTM_IH) {
+        std::vector<float> tmp((size_t)p.Cin * p.Cout);
+        for (int co = 0; co < p.Cout; ++co)
+            for (int ci = 0; ci < p.Cin; ++ci) tmp[(size_t)ci * p.Cout + co] = src[(size_t)co * p.Cin + ci];
+        VR_HIP(hipMemcpy2D(p.dev + p.co_off, (size_t)p.CoutPad * sizeof(float), tmp.data(), (size_t)p.Cout * sizeof(float),
+                           (size_t)p.Cout * sizeof(float), (size_t)p.Cin, hipMemcpyHostToDevice));
+    } else {
+        VR_HIP(hipMemcpy(p.dev, src, p.numel * sizeof(float), hipMemcpyHostToDevice));
+    }
+    affine_dirty = true;
+}
+
+void Model::get_param(const std::string& key, void* host, int64_t cap_bytes) {
+    auto it = by_key.find(key);
+    VR_CHECK(it != by_key.end(), -2, "unknown parameter key: " + key);
+    Param& p = *it->second;
+    VR_HIP(hipSetDevice(device));
+    VR_HIP(hipStreamSynchronize(stream));
+    if (p.kind == PK_NBT) {
+        VR_CHECK(cap_bytes >= 8, -2, "buffer too small");
+        *static_cast<int64_t*>(host) = p.nbt;
+        return;
+    }
+    VR_CHECK((size_t)cap_bytes >= p.numel * sizeof(float), -2, "buffer too small for " + key);
+    float* dst = static_cast<float*>(host);
+    if (p.kind == PK_CONV) {
+        std::vector<float> tmp((size_t)p.Cin * p.KK * p.CoutPad);
+        VR_HIP(hipMemcpy(tmp.data(), p.dev, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (int co = 0; co < p.Cout; ++co)
+            for (int ci = 0; ci < p.Cin; ++ci)
+                for (int k = 0; k < p.KK; ++k)
+                    dst[((size_t)co * p.Cin + ci) * p.KK + k] = tmp[((size_t)ci * p.KK + k) * p.CoutPad + co];
+    } else if (p.kind == PK_LSTM_IH) {
+        std::vector<float> tmp((size_t)p.Cin * p.Cout);
+        VR_HIP(hipMemcpy2D(tmp.data(), (size_t)p.Cout * sizeof(float), p.dev + p.co_off, (size_t)p.CoutPad * sizeof(float),
+                           (size_t)p.Cout * sizeof(float), (size_t)p.Cin, hipMemcpyDeviceToHost));
+        for (int co = 0; co < p.Cout; ++co)
+            for (int ci = 0; ci < p.Cin; ++ci) dst[(size_t)co * p.Cin + ci] = tmp[(size_t)ci * p.Cout + co];
+    } else {
+        VR_HIP(hipMemcpy(dst, p.dev, p.numel * sizeof(float), hipMemcpyDeviceToHost));
+    }
+}
+
+void Model::set_training(bool t) {
+    if (training && !t) affine_dirty = true;     // batch-stat affines must be replaced by running-stat ones
+    training = t;
+}
+
+void Model::fold_eval_affines() {
+    if (!affine_dirty) return;
+    int maxC = 1;
+    for (BN* b : bn_list) maxC = std::max(maxC, std::max(b->C, b->bcast));
+    launch_bn_fold_eval(d_fold, (int)bn_list.size(), maxC, 1e-5f, stream);
+    affine_dirty = false;
+}
+
+// =====================================================================================================
+// workspace
+// =====================================================================================================
+void Model::ensure_ws(size_t bytes) {
+    if (bytes <= ws.cap) return;
+    VR_HIP(hipStreamSynchronize(stream));
+    if (ws.base) VR_HIP(hipFree(ws.base));
+    ws.base = nullptr; ws.cap = 0;
+    const size_t want = bytes + (bytes >> 4) + (1 << 20);
+    VR_HIP(hipMalloc(reinterpret_cast<void**>(&ws.base), want));
+    ws.cap = want;
+}
+
+void Model::ensure_io(size_t bytes) {
+    if (bytes <= io.cap) return;
+    VR_HIP(hipStreamSynchronize(stream));
+    if (io.base) VR_HIP(hipFree(io.base));
+    io.base = nullptr; io.cap = 0;
+    const size_t want = bytes + (bytes >> 4) + (1 << 20);
+    VR_HIP(hipMalloc(reinterpret_cast<void**>(&io.base), want));
+    io.cap = want;
+}
+
+void Model::record_begin(int kind, double flops) {
+    if (!profiling || dry) return;
+    ProfileEntry e{};
+    VR_HIP(hipEventCreate(&e.e0));
+    VR_HIP(hipEventCreate(&e.e1));
+    e.flops = flops; e.kind = kind;
+    VR_HIP(hipEventRecord(e.e0, stream));
+    prof.push_back(e);
+}
+void Model::record_end() {
+    if (!profiling || dry) return;
+    VR_HIP(hipEventRecord(prof.back().e1, stream));
+}
+
+void Model::profile_begin() {
+    for (auto& e : prof) { hipEventDestroy(e.e0); hipEventDestroy(e.e1); }
+    prof.clear();
+    profiling = true;
+}
+
+void Model::profile_end(double* conv_ms, double* conv_flops, double* other_ms, int* launches) {
+    VR_HIP(hipStreamSynchronize(stream));
+    double cm = 0, cf = 0, om = 0;
+    int n = 0;
+    for (auto& e : prof) {
+        float ms = 0.f;
+        VR_HIP(hipEventElapsedTime(&ms, e.e0, e.e1));
+        if (e.kind == 0) { cm += ms; cf += e.flops; ++n; } else om += ms;
+        hipEventDestroy(e.e0); hipEventDestroy(e.e1);
+    }
+    prof.clear();
+    profiling = false;
+    if (conv_ms) *conv_ms = cm;
+    if (conv_flops) *conv_flops = cf;
+    if (other_ms) *other_ms = om;
+    if (launches) *launches = n;
+}
+
+void Model::tap(const std::string& name, const Tensor& t) {
+    if (record_taps && !dry) taps[name] = t;
+}
+
+int64_t Model::get_tap(const std::string& name, float* host, int64_t cap_floats, int64_t* shape4) {
+    auto it = taps.find(name);
+    VR_CHECK(it != taps.end(), -2, "no such tap: " + name);
+    const Tensor& t = it->second;
+    const int64_t n = (int64_t)t.N * t.C * t.H * t.W;
+    if (shape4) { shape4[0] = t.N; shape4[1] = t.C; shape4[2] = t.H; shape4[3] = t.W; }
+    if (!host) return n;
+    VR_CHECK(cap_floats >= n, -2, "tap buffer too small");
+    float* tmp = nullptr;
+    VR_HIP(hipMalloc(&tmp, n * sizeof(float)));
+    launch_materialize(t, tmp, stream);
+    VR_HIP(hipStreamSynchronize(stream));
+    VR_HIP(hipMemcpy(host, tmp, n * sizeof(float), hipMemcpyDeviceToHost));
+    VR_HIP(hipFree(tmp));
+    return n;
+}
+
+// =====================================================================================================
+// executor
+// =====================================================================================================
+static ConvSrc make_src(const Tensor& t, bool up, int bcastH) {
+    ConvSrc s{};
+    s.p = t.p; s.aff0 = t.aff0; s.aff1 = t.aff1 ? t.aff1 : t.aff0;
+    s.sN = t.sN; s.sC = t.sC; s.sH = t.sH;
+    s.C = t.C; s.H = t.H; s.W = t.W;
+    s.hsplit = t.hsplit; s.slope = t.slope; s.up = up ? 1 : 0; s.post = t.post;
+    s.rh = (t.H > 0) ? (float)(t.H - 1) / (float)(2 * t.H - 1) : 0.f;
+    s.rw = (t.W > 0) ? (float)(t.W - 1) / (float)(2 * t.W - 1) : 0.f;
+    if (bcastH) { s.sH = 0; s.H = bcastH; }
+    return s;
+}
+
+Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs, int N, const Tensor* out_view, const float* bias,
+                       bool batch_as_h) {
+    VR_CHECK(!srcs.empty() && srcs.size() <= 3, -2, "conv " + L.name + ": 1..3 sources");
+    ConvArgs a{};
+    a.nsrc = (int)srcs.size();
+    int Hin = -1, Win = -1, ctot = 0;
+    for (int i = 0; i < a.nsrc; ++i) {
+        const SrcSpec& sp = srcs[i];
+        a.src[i] = make_src(sp.t, sp.up, sp.bcastH);
+        const int vh = sp.up ? 2 * sp.t.H : (sp.bcastH ? sp.bcastH : sp.t.H);
+        const int vw = sp.up ? 2 * sp.t.W : sp.t.W;
+        if (Hin < 0) { Hin = vh; Win = vw; }
+        // spec_utils.crop_center (lib/spec_utils.py:8-23) is the identity for every valid shape;
+        // anything else is the reference's ValueError.
+        VR_CHECK(vh == Hin && vw == Win, -5, "h1_shape[3] must be greater than h2_shape[3] (decoder skip/upsample size mismatch in " + L.name + ")");
+        ctot += sp.t.C;
+    }
+    VR_CHECK(ctot == L.Cin, -2, "conv " + L.name + ": channel count mismatch");
+    a.c1 = a.nsrc >= 2 ? srcs[0].t.C : L.Cin;
+    a.c2 = a.nsrc >= 3 ? srcs[0].t.C + srcs[1].t.C : L.Cin;
+    a.Cin = L.Cin;
+    a.w = L.w->dev;
+    a.bias = bias;
+    a.Cout = L.Cout; a.CoutPad = L.CoutPad;
+    int Nk = N;
+    if (batch_as_h) {
+        VR_CHECK(L.KS == 1 && Hin == 1, -2, "batch-as-rows view needs a 1x1 conv on H=1 input");
+        for (int i = 0; i < a.nsrc; ++i) {
+            VR_CHECK(!a.src[i].post && !a.src[i].up, -2, "batch-as-rows: unsupported source flags");
+            a.src[i].sH = a.src[i].sN; a.src[i].sN = 0; a.src[i].H = N;
+        }
+        Hin = N; Nk = 1;
+    }
+    a.N = Nk; a.Hin = Hin; a.Win = Win;
+    a.Hout = (Hin + 2 * L.pad_h - L.dh * (L.KS - 1) - 1) / L.stride + 1;
+    a.Wout = (Win + 2 * L.pad_w - L.dw * (L.KS - 1) - 1) / L.stride + 1;
+    a.pad_h = L.pad_h; a.pad_w = L.pad_w;
+    Tensor o;
+    if (batch_as_h) {
+        o.N = N; o.C = L.Cout; o.H = 1; o.W = a.Wout;
+        if (out_view) { o.p = out_view->p; o.sN = out_view->sN; o.sC = out_view->sC; o.sH = out_view->sH; }
+        else { o.p = ws.allocf((size_t)N * L.Cout * a.Wout); o.sN = (long long)L.Cout * a.Wout; o.sC = a.Wout; o.sH = a.Wout; }
+        a.out = o.p; a.oN = 0; a.oC = o.sC; a.oH = o.sN;
+    } else {
+        o.N = N; o.C = L.Cout; o.H = a.Hout; o.W = a.Wout;
+        if (out_view) {
+            VR_CHECK(out_view->H == a.Hout && out_view->W == a.Wout && out_view->C == L.Cout, -2, "conv " + L.name + ": output view shape mismatch");
+            o.p = out_view->p; o.sN = out_view->sN; o.sC = out_view->sC; o.sH = out_view->sH;
+        } else {
+            o.p = ws.allocf((size_t)N * L.Cout * a.Hout * a.Wout);
+            o.sH = a.Wout; o.sC = (long long)a.Hout * a.Wout; o.sN = o.sC * L.Cout;
+        }
+        a.out = o.p; a.oN = o.sN; a.oC = o.sC; a.oH = o.sH;
+    }
+    const ConvShape shp{L.KS, L.stride, L.dh, L.dw};
+    const bool stats = training && L.bn;
+    size_t npt = 0;
+    if (stats) {
+        npt = conv_part_count(a, shp);
+        a.part = ws.allocf(npt * L.Cout * 2);
+    }
+    if (!dry) {
+        const double flops = 2.0 * N * (double)(batch_as_h ? 1 : a.Hout) * a.Wout * (double)L.Cout * L.Cin * L.KS * L.KS;
+        record_begin(0, flops);
+        launch_conv(a, shp, stream);
+        record_end();
+        if (stats) {
+            BNFinalizeArgs f{};
+            f.part = a.part; f.nparts = (int)npt; f.pstride = L.Cout * 2;
+            f.count = (double)N * (batch_as_h ? 1 : a.Hout) * a.Wout;
+            f.w = L.bn->w->dev; f.b = L.bn->b->dev; f.rm = L.bn->rm->dev; f.rv = L.bn->rv->dev;
+            f.affine = L.bn->affine; f.save_mean = L.bn->save_mean; f.save_invstd = L.bn->save_invstd;
+            f.C = L.Cout; f.eps = 1e-5f; f.momentum = 0.1f; f.broadcast = 0;
+            launch_bn_finalize(f, stream);
+            L.bn->nbt->nbt += 1;
+        }
+    }
+    if (L.bn) { o.aff0 = L.bn->affine; o.slope = L.slope; } else { o.aff0 = nullptr; o.slope = 1.f; }
+    return o;
+}
+
+// layers.LSTMModule.forward (lib/layers.py:124-133)
+Tensor Model::run_lstm(LSTMMod& M, const Tensor& h) {
+    const int N = h.N, nb = h.H, nf = h.W;
+    VR_CHECK(nb == M.nin, -2, "LSTM input size does not match the number of bins at dec2");
+    // 1x1 conv 2c -> 1 (+BN+ReLU): raw z [N][nb][nf]
+    float* z = ws.allocf((size_t)N * nb * nf);
+    const int nblk = launch_squeeze_conv(h, M.squeeze.w->dev, z, nullptr, true, stream);
+    float* part = training ? ws.allocf((size_t)nblk * 2) : nullptr;
+    if (!dry) {
+        launch_squeeze_conv(h, M.squeeze.w->dev, z, part, false, stream);
+        if (training) {
+            BN* b = M.squeeze.bn;
+            BNFinalizeArgs f{};
+            f.part = part; f.nparts = nblk; f.pstride = 2; f.count = (double)N * nb * nf;
+            f.w = b->w->dev; f.b = b->b->dev; f.rm = b->rm->dev; f.rv = b->rv->dev;
+            f.affine = b->affine; f.save_mean = b->save_mean; f.save_invstd = b->save_invstd;
+            f.C = 1; f.eps = 1e-5f; f.momentum = 0.1f; f.broadcast = b->bcast;
+            launch_bn_finalize(f, stream);
+            b->nbt->nbt += 1;
+        }
+    }
+    // z as [N, C=nb, H=1, W=nf] (bins become channels): the LSTM input projection is a 1x1 conv
+    Tensor zt;
+    zt.p = z; zt.N = N; zt.C = nb; zt.H = 1; zt.W = nf;
+    zt.sN = (long long)nb * nf; zt.sC = nf; zt.sH = nf;
+    zt.aff0 = M.squeeze.bn->affine; zt.slope = 0.f;
+    const int G = 4 * M.hid;
+    float* bias = ws.allocf((size_t)2 * G);
+    if (!dry) {
+        launch_add(M.b_ih_f->dev, M.b_hh_f->dev, bias, G, stream);
+        launch_add(M.b_ih_r->dev, M.b_hh_r->dev, bias + G, G, stream);
+    }
+    Tensor gx = run_conv(M.proj, {SrcSpec{zt}}, N, nullptr, bias, true);       // [N][8H][nf]
+    float* hc = ws.allocf((size_t)N * 2 * M.hid * nf);                          // [N][2H][nf]
+    if (!dry) launch_bilstm(gx.p, M.whh_f->dev, M.whh_r->dev, hc, N, nf, M.hid, stream);
+    Tensor ht;
+    ht.p = hc; ht.N = N; ht.C = 2 * M.hid; ht.H = 1; ht.W = nf;
+    ht.sN = (long long)2 * M.hid * nf; ht.sC = nf; ht.sH = nf; ht.slope = 1.f;
+    Tensor lin = run_conv(M.dense, {SrcSpec{ht}}, N, nullptr, M.dense_b->dev, true);   // [N][nb][nf] raw
+    if (!dry) launch_rows_affine_relu(lin.p, M.dense.bn->affine, N, nb, nf, stream);
+    Tensor o;                                                                   // [N,1,nb,nf], already activated
+    o.p = lin.p; o.N = N; o.C = 1; o.H = nb; o.W = nf;
+    o.sN = (long long)nb * nf; o.sC = (long long)nb * nf; o.sH = nf; o.slope = 1.f;
+    return o;
+}
+
+// nets.BaseNet.__call__ (lib/nets.py:26-41)
+Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, const Tensor* out_view) {
+    const std::string& p = B.prefix;
+    Tensor e[5];
+    e[0] = run_conv(B.enc1, in, N, nullptr, nullptr, false);
+    tap(p + ".e1", e[0]);
+    for (int i = 0; i < 4; ++i) {
+        Tensor t = run_conv(B.enc_a[i], {SrcSpec{e[i]}}, N, nullptr, nullptr, false);
+        e[i + 1] = run_conv(B.enc_b[i], {SrcSpec{t}}, N, nullptr, nullptr, false);
+        tap(p + ".e" + std::to_string(i + 2), e[i + 1]);
+    }
+    // layers.ASPPModule.forward (lib/layers.py:92-105)
+    const Tensor& x5 = e[4];
+    const int C8 = 8 * B.c;
+    float* pooled = ws.allocf((size_t)N * C8 * x5.W);
+    if (!dry) launch_avgpool_h(x5, pooled, stream);
+    Tensor pt;
+    pt.p = pooled; pt.N = N; pt.C = C8; pt.H = 1; pt.W = x5.W;
+    pt.sN = (long long)C8 * x5.W; pt.sC = x5.W; pt.sH = x5.W; pt.slope = 1.f;
+    Tensor f1 = run_conv(B.aspp_pool, {SrcSpec{pt}}, N, nullptr, nullptr, true);
+    // conv2..conv5 write channel slices of one [N, 4*C8, H, W] buffer (the concat is never built)
+    Tensor cat4;
+    cat4.N = N; cat4.C = 4 * C8; cat4.H = x5.H; cat4.W = x5.W;
+    cat4.sH = x5.W; cat4.sC = (long long)x5.H * x5.W; cat4.sN = cat4.sC * cat4.C;
+    cat4.p = ws.allocf((size_t)N * cat4.C * x5.H * x5.W);
+    cat4.aff0 = B.aspp_aff; cat4.slope = 0.f;
+    Conv* branch[4] = {&B.aspp_c2, &B.aspp_d[0], &B.aspp_d[1], &B.aspp_d[2]};
+    for (int j = 0; j < 4; ++j) {
+        Tensor v = cat4;
+        v.C = C8;
+        v.p = dry ? cat4.p : cat4.p + (long long)j * C8 * cat4.sC;
+        run_conv(*branch[j], {SrcSpec{x5}}, N, &v, nullptr, false);
+    }
+    SrcSpec s1{f1};
+    s1.bcastH = x5.H;          // bilinear from H=1 with align_corners=True is a broadcast along H
+    Tensor h = run_conv(B.aspp_bott, {s1, SrcSpec{cat4}}, N, nullptr, nullptr, false);
+    if (training && dropout_dev) {
+        int idx = (int)(&B - nets_);
+        h.post = dropout_dev + (size_t)idx * N * 8 * nout;   // [5][N][8*nout] slots, row pitch 8c
+    }
+    tap(p + ".aspp", h);
+    // decoders (lib/layers.py:51-64): upsample x2 + skip concat + conv, all inside the conv's loader
+    for (int i = 0; i < 3; ++i) {
+        SrcSpec up{h};
+        up.up = true;
+        h = run_conv(B.dec[i], {up, SrcSpec{e[3 - i]}}, N, nullptr, nullptr, false);
+        tap(p + ".dec" + std::to_string(4 - i), h);
+    }
+    Tensor l = run_lstm(B.lstm, h);
+    tap(p + ".lstm", l);
+    SrcSpec uh{h}; uh.up = true;
+    SrcSpec ul{l}; ul.up = true;
+    Tensor o = run_conv(B.dec[3], {uh, ul, SrcSpec{e[0]}}, N, out_view, nullptr, false);
+    tap(p + ".dec1", o);
+    return o;
+}
+
+// CascadedNet.forward up to (not including) `out` (lib/nets.py:86-102)
+Tensor Model::run_net(const Tensor& x) {
+    const int B = x.N, T = x.W;
+    const int bandw = max_bin / 2;
+    Tensor xl = x; xl.H = bandw;
+    Tensor xh = x; xh.H = bandw; xh.p = dry ? x.p : x.p + (long long)bandw * x.sH;
+    auto make_aux = [&](int C) {
+        Tensor t;
+        t.N = B; t.C = C; t.H = max_bin; t.W = T;
+        t.sH = T; t.sC = (long long)max_bin * T; t.sN = t.sC * C;
+        t.p = ws.allocf((size_t)B * C * max_bin * T);
+        t.slope = 0.f;
+        return t;
+    };
+    Tensor aux1 = make_aux(nout / 4), aux2 = make_aux(nout / 2);
+    auto half = [&](const Tensor& a, int which) {
+        Tensor v = a; v.H = bandw;
+        if (which && !dry) v.p = a.p + (long long)bandw * a.sH;
+        return v;
+    };
+    Tensor v;
+    Tensor l1r = run_basenet(nets_[0], {SrcSpec{xl}}, B, nullptr);
+    v = half(aux1, 0);
+    Tensor l1 = run_conv(tail1, {SrcSpec{l1r}}, B, &v, nullptr, false);
+    v = half(aux1, 1);
+    Tensor h1 = run_basenet(nets_[1], {SrcSpec{xh}}, B, &v);
+    tap("l1", l1); tap("h1", h1);
+    Tensor l2r = run_basenet(nets_[2], {SrcSpec{xl}, SrcSpec{l1}}, B, nullptr);
+    v = half(aux2, 0);
+    Tensor l2 = run_conv(tail2, {SrcSpec{l2r}}, B, &v, nullptr, false);
+    v = half(aux2, 1);
+    Tensor h2 = run_basenet(nets_[3], {SrcSpec{xh}, SrcSpec{h1}}, B, &v);
+    tap("l2", l2); tap("h2", h2);
+    aux1.aff0 = l1.aff0; aux1.aff1 = h1.aff0; aux1.hsplit = bandw;
+    aux2.aff0 = l2.aff0; aux2.aff1 = h2.aff0; aux2.hsplit = bandw;
+    Tensor xf = x; xf.H = max_bin;
+    Tensor f3 = run_basenet(nets_[4], {SrcSpec{xf}, SrcSpec{aux1}, SrcSpec{aux2}}, B, nullptr);
+    return f3;
+}
+
+void Model::plan_and_reserve(int B, int T, size_t extra_bytes) {
+    Arena saved = ws;
+    ws.dry = true; ws.base = nullptr; ws.off = 0; ws.peak = 0;
+    dry = true;
+    Tensor x;
+    x.p = reinterpret_cast<float*>(uintptr_t(256));
+    x.N = B; x.C = 2; x.H = max_bin; x.W = T; x.sH = T; x.sC = (long long)output_bin * T; x.sN = 2 * x.sC;
+    try { run_net(x); } catch (...) { dry = false; ws = saved; throw; }
+    dry = false;
+    const size_t need = ws.peak + extra_bytes + 4096;
+    ws = saved;
+    ensure_ws(need);
+    ws.reset();
+}
+
+static void check_T(int T, int offset, int mode) {
+    VR_CHECK(T > 0 && T % 16 == 0, -5, "h1_shape[3] must be greater than h2_shape[3] (frames must be a multiple of 16)");
+    if (mode != 0) VR_CHECK(T - 2 * offset > 0, -6, "assert mask.size()[3] > 0 (frames must exceed 2*offset)");
+}
+
+__global__ void mul_crop_kernel(const float* __restrict__ x, float* __restrict__ m, int T, int Wm, int off, long long total) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int w = (int)(gid % Wm);
+    const long long row = gid / Wm;
+    m[gid] *= x[row * T + off + w];
+}
+
+void Model::forward_api(const float* x, bool x_on_device, int B, int T, int mode, float* out, bool out_on_device) {
+    VR_HIP(hipSetDevice(device));
+    VR_CHECK(B > 0, -2, "batch must be positive");
+    check_T(T, offset, mode);
+    const size_t in_floats = (size_t)B * 2 * output_bin * T;
+    const int Wm = mode == 0 ? T : T - 2 * offset;
+    const size_t out_floats = (size_t)B * 2 * output_bin * Wm;
+    plan_and_reserve(B, T, (in_floats + out_floats) * sizeof(float) + 1024);
+    if (!training) fold_eval_affines();
+    float* xd = ws.allocf(in_floats);
+    float* od = out_on_device ? out : ws.allocf(out_floats);
+    if (x_on_device) VR_HIP(hipMemcpyAsync(xd, x, in_floats * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    else VR_HIP(hipMemcpyAsync(xd, x, in_floats * sizeof(float), hipMemcpyHostToDevice, stream));
+    Tensor xt;
+    xt.p = xd; xt.N = B; xt.C = 2; xt.H = max_bin; xt.W = T;
+    xt.sH = T; xt.sC = (long long)output_bin * T; xt.sN = 2 * xt.sC; xt.slope = 1.f;
+    if (record_taps) taps.clear();
+    Tensor f3 = run_net(xt);
+    HeadDst d{};
+    d.p = od; d.dH = Wm; d.dC = (long long)output_bin * Wm; d.dN = 2 * d.dC;
+    d.w_lo = mode == 0 ? 0 : offset; d.w_hi = mode == 0 ? T : T - offset; d.pad_rows = output_bin - max_bin;
+    launch_head_sigmoid(f3, out_w->dev, d, stream);
+    if (mode == 2) {
+        const long long total = (long long)out_floats;
+        hipLaunchKernelGGL(mul_crop_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, xd, od, T, Wm,
+                           offset, total);
+        VR_HIP(hipGetLastError());
+    }
+    if (!out_on_device) VR_HIP(hipMemcpyAsync(out, od, out_floats * sizeof(float), hipMemcpyDeviceToHost, stream));
+    VR_HIP(hipStreamSynchronize(stream));
+    if (training) affine_dirty = true;
+}
+
+// =====================================================================================================
+// signal path
+// =====================================================================================================
+void Model::stft_api(const float* wave, bool on_dev, long long L, float* spec, bool spec_on_dev) {
+    VR_HIP(hipSetDevice(device));
+    VR_CHECK(L > 0, -2, "empty wave");
+    const int T = 1 + (int)(L / hop);
+    const size_t spec_f = (size_t)2 * output_bin * T * 2;
+    ensure_io(((size_t)2 * L + spec_f) * sizeof(float) + 4096);
+    io.reset();
+    const float* wd = wave;
+    if (!on_dev) {
+        float* tmp = io.allocf((size_t)2 * L);
+        VR_HIP(hipMemcpyAsync(tmp, wave, (size_t)2 * L * sizeof(float), hipMemcpyHostToDevice, stream));
+        wd = tmp;
+    }
+    float* sd = spec_on_dev ? spec : io.allocf(spec_f);
+    launch_stft(plan, wd, L, hop, T, reinterpret_cast<float2*>(sd), stream);
+    if (!spec_on_dev) VR_HIP(hipMemcpyAsync(spec, sd, spec_f * sizeof(float), hipMemcpyDeviceToHost, stream));
+    VR_HIP(hipStreamSynchronize(stream));
+}
+
+void Model::istft_api(const float* spec, bool on_dev, int T, float* wave, bool wave_on_dev) {
+    VR_HIP(hipSetDevice(device));
+    VR_CHECK(T > 0, -2, "empty spectrogram");
+    const size_t spec_f = (size_t)2 * output_bin * T * 2;
+    const size_t out_f = (size_t)2 * hop * (T - 1);
+    const size_t frames_f = (size_t)2 * T * n_fft;
+    ensure_io((spec_f + out_f + frames_f) * sizeof(float) + 8192);
+    io.reset();
+    const float* sd = spec;
+    if (!on_dev) {
+        float* tmp = io.allocf(spec_f);
+        VR_HIP(hipMemcpyAsync(tmp, spec, spec_f * sizeof(float), hipMemcpyHostToDevice, stream));
+        sd = tmp;
+    }
+    float* frames = io.allocf(frames_f);
+    float* wd = wave_on_dev ? wave : io.allocf(out_f + 4);
+    launch_istft(plan, reinterpret_cast<const float2*>(sd), hop, T, frames, wd, stream);
+    if (!wave_on_dev && out_f) VR_HIP(hipMemcpyAsync(wave, wd, out_f * sizeof(float), hipMemcpyDeviceToHost, stream));
+    VR_HIP(hipStreamSynchronize(stream));
+}
+
+// dataset.make_padding (lib/dataset.py:198-205)
+static void make_padding(int width, int cropsize, int offset, int& left, int& right, int& roi) {
+    left = offset;
+    roi = cropsize - offset * 2;
+    if (roi == 0) roi = cropsize;
+    right = roi - (width % roi) + left;
+}
+
+// Separator.separate / separate_tta (inference.py:70-102) on device-resident spectrograms.
+// spec_d, y_d, v_d: device [2][bins][T] complex64.  scratch comes from `io` (caller reserved).
+static size_t separate_scratch_floats(int bins, int T, int cropsize, int offset, int tta) {
+    int l, r, roi;
+    make_padding(T, cropsize, offset, l, r, roi);
+    const size_t Wpad2 = (size_t)T + l + r + roi;
+    return 2 * (size_t)2 * bins * Wpad2 * (tta ? 2 : 1) + 4096;
+}
+
+void Model::separate_api(const float* spec, bool on_dev, int T, int tta, int batchsize, int cropsize, float* y_spec,
+                         float* v_spec, bool out_on_dev) {
+    VR_HIP(hipSetDevice(device));
+    VR_CHECK(T > 0, -2, "empty spectrogram");
+    VR_CHECK(!training, -2, "separate() runs in eval mode (inference.py:52); call vr_set_mode(h, 0) first");
+    check_T(cropsize, offset, 1);
+    VR_CHECK(cropsize - 2 * offset > 0, -6, "cropsize must exceed 2*offset");
+    const int bins = output_bin;
+    const size_t spec_f = (size_t)2 * bins * T * 2;
+    int pad_l, pad_r, roi;
+    make_padding(T, cropsize, offset, pad_l, pad_r, roi);
+    const size_t scratch = separate_scratch_floats(bins, T, cropsize, offset, tta);
+    if (!on_dev || !out_on_dev) {
+        // host-facing call: stage through `io` (the wave-level entry point reserves for itself)
+        ensure_io((3 * spec_f + scratch) * sizeof(float) + 65536);
+        io.reset();
+    }
+    const float* sd = spec;
+    if (!on_dev) {
+        float* tmp = io.allocf(spec_f);
+        VR_HIP(hipMemcpyAsync(tmp, spec, spec_f * sizeof(float), hipMemcpyHostToDevice, stream));
+        sd = tmp;
+    }
+    float* yd = out_on_dev ? y_spec : io.allocf(spec_f);
+    float* vd = out_on_dev ? v_spec : io.allocf(spec_f);
+    unsigned* stats = static_cast<unsigned*>(io.alloc(64));
+    float* in_aff = io.allocf(16);
+    const int npass = tta ? 2 : 1;
+    float* mask[2] = {nullptr, nullptr};
+    int Wm[2] = {0, 0};
+    int max_patches = 0;
+    for (int ps = 0; ps < npass; ++ps) {
+        const int Wpad = T + pad_l + pad_r + (ps ? roi : 0);
+        max_patches = std::max(max_patches, (Wpad - 2 * offset) / roi);
+    }
+    const int bs = (batchsize <= 0) ? max_patches : std::min(batchsize, max_patches);
+    plan_and_reserve(bs, cropsize, 0);
+    fold_eval_affines();
+    for (int ps = 0; ps < npass; ++ps) {
+        const int pl = pad_l + (ps ? roi / 2 : 0), pr = pad_r + (ps ? roi / 2 : 0);
+        const int Wpad = T + pl + pr;
+        const int patches = (Wpad - 2 * offset) / roi;
+        float* mag = io.allocf((size_t)2 * bins * Wpad);
+        Wm[ps] = patches * roi;
+        mask[ps] = io.allocf((size_t)2 * bins * Wm[ps]);
+        VR_HIP(hipMemsetAsync(mag, 0, (size_t)2 * bins * Wpad * sizeof(float), stream));
+        launch_stats_init(stats, stream);
+        launch_mag_pad(reinterpret_cast<const float2*>(sd), bins, T, mag, Wpad, pl, stats, stream);
+        launch_coef_affine(stats, tta ? 1 : 0, in_aff, stream);
+        for (int i = 0; i < patches; i += bs) {
+            const int nb = std::min(bs, patches - i);
+            ws.reset();
+            Tensor x;
+            x.p = mag + (size_t)i * roi; x.N = nb; x.C = 2; x.H = max_bin; x.W = cropsize;
+            x.sN = roi; x.sC = (long long)bins * Wpad; x.sH = Wpad;
+            x.aff0 = in_aff; x.slope = 1.f;
+            Tensor f3 = run_net(x);
+            HeadDst d{};
+            d.p = mask[ps] + (size_t)i * roi; d.dN = roi; d.dC = (long long)bins * Wm[ps]; d.dH = Wm[ps];
+            d.w_lo = offset; d.w_hi = cropsize - offset; d.pad_rows = output_bin - max_bin;
+            launch_head_sigmoid(f3, out_w->dev, d, stream);
+        }
+    }
+    launch_apply_mask(reinterpret_cast<const float2*>(sd), bins, T, mask[0], Wm[0], tta ? mask[1] : nullptr, Wm[1], roi / 2,
+                      reinterpret_cast<float2*>(yd), reinterpret_cast<float2*>(vd), stream);
+    if (!out_on_dev) {
+        VR_HIP(hipMemcpyAsync(y_spec, yd, spec_f * sizeof(float), hipMemcpyDeviceToHost, stream));
+        VR_HIP(hipMemcpyAsync(v_spec, vd, spec_f * sizeof(float), hipMemcpyDeviceToHost, stream));
+    }
+    VR_HIP(hipStreamSynchronize(stream));
+}
+
+void Model::separate_wave_api(const float* wave, bool on_dev, long long L, int tta, int batchsize, int cropsize,
+                              float* y_wave, float* v_wave, bool out_on_dev) {
+    VR_HIP(hipSetDevice(device));
+    VR_CHECK(L >= hop, -2, "wave shorter than one hop");
+    const int T = 1 + (int)(L / hop);
+    const int bins = output_bin;
+    const size_t spec_f = (size_t)2 * bins * T * 2;
+    const size_t out_f = (size_t)2 * hop * (T - 1);
+    const size_t frames_f = (size_t)2 * T * n_fft;
+    const size_t scratch = separate_scratch_floats(bins, T, cropsize, offset, tta);
+    ensure_io(((size_t)2 * L + 3 * spec_f + 2 * out_f + frames_f + scratch) * sizeof(float) + 65536);
+    io.reset();
+    const float* wd = wave;
+    if (!on_dev) {
+        float* tmp = io.allocf((size_t)2 * L);
+        VR_HIP(hipMemcpyAsync(tmp, wave, (size_t)2 * L * sizeof(float), hipMemcpyHostToDevice, stream));
+        wd = tmp;
+    }
+    float* spec = io.allocf(spec_f);
+    float* ys = io.allocf(spec_f);
+    float* vs = io.allocf(spec_f);
+    float* frames = io.allocf(frames_f);
+    float* yw = out_on_dev ? y_wave : io.allocf(out_f + 4);
+    float* vw = out_on_dev ? v_wave : io.allocf(out_f + 4);
+    launch_stft(plan, wd, L, hop, T, reinterpret_cast<float2*>(spec), stream);
+    separate_api(spec, true, T, tta, batchsize, cropsize, ys, vs, true);
+    launch_istft(plan, reinterpret_cast<const float2*>(ys), hop, T, frames, yw, stream);
+    launch_istft(plan, reinterpret_cast<const float2*>(vs), hop, T, frames, vw, stream);
+    if (!out_on_dev && out_f) {
+        VR_HIP(hipMemcpyAsync(y_wave, yw, out_f * sizeof(float), hipMemcpyDeviceToHost, stream));
+        VR_HIP(hipMemcpyAsync(v_wave, vw, out_f * sizeof(float), hipMemcpyDeviceToHost, stream));
+    }
+    VR_HIP(hipStreamSynchronize(stream));
+}
+
+// =====================================================================================================
+// unit-test hook: one conv through the MFMA kernel with a single dense source
+// =====================================================================================================
+void Model::debug_conv(const float* x, int N, int Cin, int H, int W, const float* w_oihw, int Cout, int KS, int stride,
+                       int dh, int dw, int up, const float* aff, float slope, const float* bias, float* out,
+                       float* stats_out) {
+    VR_HIP(hipSetDevice(device));
+    const int KK = KS * KS, CoutPad = round_up(Cout, 32);
+    const int Hin = up ? 2 * H : H, Win = up ? 2 * W : W;
+    const int pad_h = KS == 1 ? 0 : dh, pad_w = KS == 1 ? 0 : dw;
+    const int Hout = (Hin + 2 * pad_h - dh * (KS - 1) - 1) / stride + 1;
+    const int Wout = (Win + 2 * pad_w - dw * (KS - 1) - 1) / stride + 1;
+    std::vector<float> wk((size_t)Cin * KK * CoutPad, 0.f);
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int k = 0; k < KK; ++k) wk[((size_t)ci * KK + k) * CoutPad + co] = w_oihw[((size_t)co * Cin + ci) * KK + k];
+    float *dx, *dw_, *dout, *daff = nullptr, *dbias = nullptr, *dpart = nullptr;
+    const size_t xin = (size_t)N * Cin * H * W, xout = (size_t)N * Cout * Hout * Wout;
+    VR_HIP(hipMalloc(&dx, xin * 4)); VR_HIP(hipMalloc(&dw_, wk.size() * 4)); VR_HIP(hipMalloc(&dout, xout * 4));
+    VR_HIP(hipMemcpy(dx, x, xin * 4, hipMemcpyHostToDevice));
+    VR_HIP(hipMemcpy(dw_, wk.data(), wk.size() * 4, hipMemcpyHostToDevice));
+    if (aff) { VR_HIP(hipMalloc(&daff, (size_t)Cin * 8)); VR_HIP(hipMemcpy(daff, aff, (size_t)Cin * 8, hipMemcpyHostToDevice)); }
+    if (bias) { VR_HIP(hipMalloc(&dbias, (size_t)Cout * 4)); VR_HIP(hipMemcpy(dbias, bias, (size_t)Cout * 4, hipMemcpyHostToDevice)); }
+    Tensor t;
+    t.p = dx; t.N = N; t.C = Cin; t.H = H; t.W = W; t.sH = W; t.sC = (long long)H * W; t.sN = t.sC * Cin;
+    t.aff0 = daff; t.slope = slope;
+    ConvArgs a{};
+    a.nsrc = 1; a.src[0] = make_src(t, up != 0, 0); a.c1 = a.c2 = Cin; a.Cin = Cin;
+    a.w = dw_; a.bias = dbias; a.Cout = Cout; a.CoutPad = CoutPad;
+    a.out = dout; a.oH = Wout; a.oC = (long long)Hout * Wout; a.oN = a.oC * Cout;
+    a.N = N; a.Hout = Hout; a.Wout = Wout; a.Hin = Hin; a.Win = Win; a.pad_h = pad_h; a.pad_w = pad_w;
+    const ConvShape shp{KS, stride, dh, dw};
+    size_t npt = 0;
+    if (stats_out) { npt = conv_part_count(a, shp); VR_HIP(hipMalloc(&dpart, npt * Cout * 8)); a.part = dpart; }
+    launch_conv(a, shp, stream);
+    VR_HIP(hipStreamSynchronize(stream));
+    VR_HIP(hipMemcpy(out, dout, xout * 4, hipMemcpyDeviceToHost));
+    if (stats_out) {
+        std::vector<float> part(npt * Cout * 2);
+        VR_HIP(hipMemcpy(part.data(), dpart, part.size() * 4, hipMemcpyDeviceToHost));
+        for (int c = 0; c < Cout; ++c) {
+            double s1 = 0, s2 = 0;
+            for (size_t i = 0; i < npt; ++i) { s1 += part[(i * Cout + c) * 2]; s2 += part[(i * Cout + c) * 2 + 1]; }
+            stats_out[2 * c] = (float)s1; stats_out[2 * c + 1] = (float)s2;
+        }
+    }
+    hipFree(dx); hipFree(dw_); hipFree(dout); hipFree(daff); hipFree(dbias); hipFree(dpart);
+}
+
+}  // namespace vr

@@ -1,0 +1,243 @@
+// HBM-bound kernels around the conv stack: thin 1x1 convs (Cout 1/2), the mask head, frequency
+// average pool, BatchNorm statistics bookkeeping.  All are streaming kernels: 16-byte loads along
+// the contiguous time axis, one pass over the data, nothing re-read.
+#include "kernels.h"
+
+namespace vr {
+
+__device__ __forceinline__ float act1(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+__device__ __forceinline__ void load_aff(const Tensor& x, int h, int c, float& sc, float& sh) {
+    const float* aff = (h < x.hsplit) ? x.aff0 : x.aff1;
+    sc = 1.f; sh = 0.f;
+    if (aff) { sc = aff[2 * c]; sh = aff[2 * c + 1]; }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Thin 1x1 conv over channels, CO outputs, 4 consecutive frames per thread.
+//   FINAL: sigmoid + window/crop + replicate rows (mask head, lib/nets.py:109-115,127-128)
+//   else : raw store to out[n][h][w] (+ per-block sum/sumsq partials for BatchNorm batch stats)
+// ---------------------------------------------------------------------------------------------------
+template <int CO, bool FINAL>
+__global__ __launch_bounds__(256) void thin_conv_kernel(Tensor x, const float* __restrict__ w, HeadDst d,
+                                                        float* out, float* part) {
+    const int W4 = x.W >> 2;
+    const long long total = (long long)x.N * x.H * W4;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    if (gid < total) {
+        const int w4 = (int)(gid % W4);
+        const long long t = gid / W4;
+        const int h = (int)(t % x.H);
+        const int n = (int)(t / x.H);
+        float acc[CO][4];
+#pragma unroll
+        for (int o = 0; o < CO; ++o)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[o][j] = 0.f;
+        const float* base = x.p + (long long)n * x.sN + (long long)h * x.sH + w4 * 4;
+        for (int c = 0; c < x.C; ++c) {
+            float sc, sh;
+            load_aff(x, h, c, sc, sh);
+            const float4 r = *reinterpret_cast<const float4*>(base + (long long)c * x.sC);
+            const float v[4] = {act1(fmaf(r.x, sc, sh), x.slope), act1(fmaf(r.y, sc, sh), x.slope),
+                                act1(fmaf(r.z, sc, sh), x.slope), act1(fmaf(r.w, sc, sh), x.slope)};
+#pragma unroll
+            for (int o = 0; o < CO; ++o) {
+                const float wc = w[o * x.C + c];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[o][j] = fmaf(wc, v[j], acc[o][j]);
+            }
+        }
+        if constexpr (FINAL) {
+#pragma unroll
+            for (int o = 0; o < CO; ++o) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int wcol = w4 * 4 + j;
+                    if (wcol < d.w_lo || wcol >= d.w_hi) continue;
+                    const float m = 1.f / (1.f + __expf(-acc[o][j]));
+                    float* dst = d.p + (long long)n * d.dN + (long long)o * d.dC + (wcol - d.w_lo);
+                    dst[(long long)h * d.dH] = m;
+                    if (h == x.H - 1)
+                        for (int e = 1; e <= d.pad_rows; ++e) dst[(long long)(h + e) * d.dH] = m;
+                }
+            }
+        } else {
+            float4 o4 = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+            *reinterpret_cast<float4*>(out + ((long long)n * x.H + h) * x.W + w4 * 4) = o4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s1 += acc[0][j]; s2 = fmaf(acc[0][j], acc[0][j], s2); }
+        }
+    }
+    if constexpr (!FINAL) {
+        if (part) {
+            __shared__ float red[8];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+            const int wave = threadIdx.x >> 6;
+            if ((threadIdx.x & 63) == 0) { red[wave * 2] = s1; red[wave * 2 + 1] = s2; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                part[blockIdx.x * 2 + 0] = red[0] + red[2] + red[4] + red[6];
+                part[blockIdx.x * 2 + 1] = red[1] + red[3] + red[5] + red[7];
+            }
+        }
+    }
+}
+
+static void check_vec4(const Tensor& x) {
+    VR_CHECK(x.W % 4 == 0 && x.sN % 4 == 0 && x.sC % 4 == 0 && x.sH % 4 == 0 &&
+                 (reinterpret_cast<uintptr_t>(x.p) & 15) == 0,
+             -2, "thin conv needs 16-byte aligned rows (frames % 4 == 0)");
+}
+
+void launch_head_sigmoid(const Tensor& x, const float* w, const HeadDst& d, hipStream_t st) {
+    check_vec4(x);
+    const long long total = (long long)x.N * x.H * (x.W / 4);
+    const int grid = (int)((total + 255) / 256);
+    hipLaunchKernelGGL((thin_conv_kernel<2, true>), dim3(grid), dim3(256), 0, st, x, w, d, nullptr, nullptr);
+    VR_HIP(hipGetLastError());
+}
+
+int launch_squeeze_conv(const Tensor& x, const float* w, float* out, float* part, bool dry, hipStream_t st) {
+    const long long total = (long long)x.N * x.H * (x.W / 4);
+    const int grid = (int)((total + 255) / 256);
+    if (dry) return grid;
+    check_vec4(x);
+    HeadDst d{};
+    hipLaunchKernelGGL((thin_conv_kernel<1, false>), dim3(grid), dim3(256), 0, st, x, w, d, out, part);
+    VR_HIP(hipGetLastError());
+    return grid;
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ void avgpool_h_kernel(Tensor x, float* out) {
+    const int total = x.N * x.C * x.W;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int w = gid % x.W;
+    const int c = (gid / x.W) % x.C;
+    const int n = gid / (x.W * x.C);
+    const float* base = x.p + (long long)n * x.sN + (long long)c * x.sC + w;
+    float s = 0.f;
+    for (int h = 0; h < x.H; ++h) {
+        float sc, sh;
+        load_aff(x, h, c, sc, sh);
+        s += act1(fmaf(base[(long long)h * x.sH], sc, sh), x.slope);
+    }
+    out[gid] = s / (float)x.H;
+}
+
+void launch_avgpool_h(const Tensor& x, float* out, hipStream_t st) {
+    const int total = x.N * x.C * x.W;
+    hipLaunchKernelGGL(avgpool_h_kernel, dim3((total + 255) / 256), dim3(256), 0, st, x, out);
+    VR_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Eval mode: affine = (w / sqrt(running_var + eps), b - running_mean * scale) for every BatchNorm.
+__global__ void bn_fold_eval_kernel(const BNFoldDesc* descs, float eps) {
+    const BNFoldDesc d = descs[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int rows = d.bcast ? d.bcast : d.C;
+    if (i >= rows) return;
+    const int c = d.bcast ? 0 : i;
+    const float scale = d.w[c] / sqrtf(d.rv[c] + eps);
+    d.affine[2 * i] = scale;
+    d.affine[2 * i + 1] = d.b[c] - d.rm[c] * scale;
+}
+
+void launch_bn_fold_eval(const BNFoldDesc* d_descs, int ndesc, int maxC, float eps, hipStream_t st) {
+    hipLaunchKernelGGL(bn_fold_eval_kernel, dim3((maxC + 127) / 128, ndesc), dim3(128), 0, st, d_descs, eps);
+    VR_HIP(hipGetLastError());
+}
+
+// Train mode: reduce per-block partials (fp64), produce the affine, update running stats with the
+// unbiased variance (torch BatchNorm semantics, momentum 0.1), save mean / invstd for backward.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(BNFinalizeArgs a) {
+    const int c = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < a.nparts; i += 256) {
+        s1 += (double)a.part[(long long)i * a.pstride + c * 2 + 0];
+        s2 += (double)a.part[(long long)i * a.pstride + c * 2 + 1];
+    }
+    __shared__ double r1[256], r2[256];
+    r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) { r1[threadIdx.x] += r1[threadIdx.x + off]; r2[threadIdx.x] += r2[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    __shared__ float sh_scale, sh_shift;
+    if (threadIdx.x == 0) {
+        const double mean = r1[0] / a.count;
+        double var = r2[0] / a.count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+        const float scale = a.w[c] * invstd;
+        const float shift = a.b[c] - (float)mean * scale;
+        sh_scale = scale; sh_shift = shift;
+        if (!a.broadcast) { a.affine[2 * c] = scale; a.affine[2 * c + 1] = shift; }
+        if (a.save_mean) { a.save_mean[c] = (float)mean; a.save_invstd[c] = invstd; }
+        const double unbiased = a.count > 1.0 ? var * a.count / (a.count - 1.0) : var;
+        a.rm[c] = (1.f - a.momentum) * a.rm[c] + a.momentum * (float)mean;
+        a.rv[c] = (1.f - a.momentum) * a.rv[c] + a.momentum * (float)unbiased;
+    }
+    if (a.broadcast) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < a.broadcast; i += 256) { a.affine[2 * i] = sh_scale; a.affine[2 * i + 1] = sh_shift; }
+    }
+}
+
+void launch_bn_finalize(const BNFinalizeArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(a.C), dim3(256), 0, st, a);
+    VR_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ void rows_affine_relu_kernel(float* x, const float* aff, int R, int W, long long total) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int r = (int)((gid / W) % R);
+    const float v = fmaf(x[gid], aff[2 * r], aff[2 * r + 1]);
+    x[gid] = v > 0.f ? v : 0.f;
+}
+
+void launch_rows_affine_relu(float* x, const float* aff, int N, int R, int W, hipStream_t st) {
+    const long long total = (long long)N * R * W;
+    hipLaunchKernelGGL(rows_affine_relu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, aff, R, W, total);
+    VR_HIP(hipGetLastError());
+}
+
+__global__ void add_kernel(const float* a, const float* b, float* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+
+void launch_add(const float* a, const float* b, float* out, int n, hipStream_t st) {
+    hipLaunchKernelGGL(add_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, b, out, n);
+    VR_HIP(hipGetLastError());
+}
+
+__global__ void materialize_kernel(Tensor x, float* out, long long total) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int w = (int)(gid % x.W);
+    long long t = gid / x.W;
+    const int h = (int)(t % x.H); t /= x.H;
+    const int c = (int)(t % x.C);
+    const int n = (int)(t / x.C);
+    float sc, sh;
+    load_aff(x, h, c, sc, sh);
+    const float raw = x.p[(long long)n * x.sN + (long long)c * x.sC + (long long)h * x.sH + w];
+    out[gid] = act1(fmaf(raw, sc, sh), x.slope);
+}
+
+void launch_materialize(const Tensor& x, float* out, hipStream_t st) {
+    const long long total = (long long)x.N * x.C * x.H * x.W;
+    hipLaunchKernelGGL(materialize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, out, total);
+    VR_HIP(hipGetLastError());
+}
+
+}  // namespace vr

@@ -1,0 +1,227 @@
+// STFT / iSTFT and the spectrogram-side glue of inference.Separator, all device-resident.
+//
+//  K1  stft         : librosa.stft semantics at the reference call site lib/spec_utils.py:26-31
+//                     (periodic Hann, centre zero-padding n_fft/2, frames 1 + L//hop, complex64).
+//  K2  mag_pad      : |X| into the zero-padded crop source + the two normalisers the reference
+//                     uses (inference.py:74 max|X|; inference.py:87,94 numpy's lexicographic
+//                     complex max).
+//  K14 istft        : librosa.istft at lib/spec_utils.py:157-165 (irfft * window, overlap-add,
+//                     / window-sum-square where > tiny, trim n_fft/2) -> hop*(T-1) samples.
+//      apply_mask   : inference.py:26-40 (y = mask*X, v = (1-mask)*X; TTA average :97-98).
+// One workgroup per frame; radix-2 FFT in LDS.  These stages are HBM-bound streaming work that is
+// <1 % of the pipeline, kept simple and exact-ordered.
+#include "kernels.h"
+
+#include <cfloat>
+
+namespace vr {
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// In-place radix-2 DIT FFT on x[0..n) (already in bit-reversed order). tw[k] = exp(-2*pi*i*k/n).
+__device__ __forceinline__ void fft_lds(float2* x, const float2* __restrict__ tw, int n, int log2n) {
+    const int half_n = n >> 1;
+    for (int s = 0; s < log2n; ++s) {
+        const int half = 1 << s;
+        __syncthreads();
+        for (int b = threadIdx.x; b < half_n; b += blockDim.x) {
+            const int pos = b & (half - 1);
+            const int i = ((b >> s) << (s + 1)) + pos;
+            const int j = i + half;
+            const float2 w = tw[pos << (log2n - 1 - s)];
+            const float2 t = cmul(w, x[j]);
+            const float2 u = x[i];
+            x[i] = make_float2(u.x + t.x, u.y + t.y);
+            x[j] = make_float2(u.x - t.x, u.y - t.y);
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void stft_kernel(FFTPlan pl, const float* __restrict__ wave, long long L,
+                                                   int hop, int T, float2* __restrict__ spec) {
+    extern __shared__ __attribute__((aligned(16))) float2 xs[];
+    const int n = pl.n_fft, t = blockIdx.x, ch = blockIdx.y;
+    const float* wv = wave + (long long)ch * L;
+    const long long start = (long long)t * hop - n / 2;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const long long p = start + i;
+        const float v = (p >= 0 && p < L) ? wv[p] * pl.window[i] : 0.f;
+        const int r = __brev((unsigned)i) >> (32 - pl.log2n);
+        xs[r] = make_float2(v, 0.f);
+    }
+    fft_lds(xs, pl.twiddle, n, pl.log2n);
+    const int bins = n / 2 + 1;
+    for (int k = threadIdx.x; k < bins; k += blockDim.x)
+        spec[((long long)ch * bins + k) * T + t] = xs[k];
+}
+
+void launch_stft(const FFTPlan& pl, const float* wave, long long L, int hop, int T, float2* spec, hipStream_t st) {
+    hipLaunchKernelGGL(stft_kernel, dim3(T, 2), dim3(256), pl.n_fft * sizeof(float2), st, pl, wave, L, hop, T, spec);
+    VR_HIP(hipGetLastError());
+}
+
+// irfft(spec[:, t]) * window -> frames[ch][t][0..n)
+__global__ __launch_bounds__(256) void istft_frame_kernel(FFTPlan pl, const float2* __restrict__ spec, int T,
+                                                          float* __restrict__ frames) {
+    extern __shared__ __attribute__((aligned(16))) float2 xs[];
+    const int n = pl.n_fft, t = blockIdx.x, ch = blockIdx.y;
+    const int bins = n / 2 + 1;
+    const float2* sp = spec + (long long)ch * bins * T + t;
+    // inverse via forward FFT of the conjugate spectrum (Hermitian-extended); imaginary parts of
+    // the DC and Nyquist bins are ignored like numpy's irfft does.
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        float2 v;
+        if (k < bins) {
+            v = sp[(long long)k * T];
+            v.y = -v.y;
+            if (k == 0 || k == n / 2) v.y = 0.f;
+        } else {
+            v = sp[(long long)(n - k) * T];      // conj(conj(X[n-k])) = X[n-k]
+        }
+        const int r = __brev((unsigned)k) >> (32 - pl.log2n);
+        xs[r] = v;
+    }
+    fft_lds(xs, pl.twiddle, n, pl.log2n);
+    const float inv = 1.f / (float)n;
+    float* fr = frames + ((long long)ch * T + t) * n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) fr[i] = xs[i].x * inv * pl.window[i];
+}
+
+__global__ void istft_ola_kernel(FFTPlan pl, const float* __restrict__ frames, int hop, int T, long long out_len,
+                                 float* __restrict__ wave) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ch = blockIdx.y;
+    if (p >= out_len) return;
+    const int n = pl.n_fft;
+    const long long q = p + n / 2;
+    long long t_hi = q / hop;
+    if (t_hi > T - 1) t_hi = T - 1;
+    long long t_lo = (q - n + hop) / hop;          // smallest t with t*hop + n > q
+    if (q - n + 1 <= 0) t_lo = 0;
+    if (t_lo < 0) t_lo = 0;
+    float acc = 0.f, wss = 0.f;
+    for (long long t = t_lo; t <= t_hi; ++t) {
+        const int i = (int)(q - t * hop);
+        if (i < 0 || i >= n) continue;
+        acc += frames[((long long)ch * T + t) * n + i];
+        const float w = pl.window[i];
+        wss = fmaf(w, w, wss);
+    }
+    wave[(long long)ch * out_len + p] = (wss > FLT_MIN) ? acc / wss : acc;
+}
+
+void launch_istft(const FFTPlan& pl, const float2* spec, int hop, int T, float* frames, float* wave, hipStream_t st) {
+    hipLaunchKernelGGL(istft_frame_kernel, dim3(T, 2), dim3(256), pl.n_fft * sizeof(float2), st, pl, spec, T, frames);
+    VR_HIP(hipGetLastError());
+    const long long out_len = (long long)hop * (T - 1);
+    if (out_len > 0) {
+        hipLaunchKernelGGL(istft_ola_kernel, dim3((unsigned)((out_len + 255) / 256), 2), dim3(256), 0, st, pl, frames,
+                           hop, T, out_len, wave);
+        VR_HIP(hipGetLastError());
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned ord32(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unord32(unsigned o) {
+    const unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(u);
+}
+
+__global__ void stats_init_kernel(unsigned* stats) {
+    stats[0] = 0u;                                      // max |X| bits (>= 0)
+    stats[1] = 0u;
+    // lexicographic max starts at 0+0j: the zero padding is part of the array the reference reduces
+    unsigned long long key = ((unsigned long long)ord32(0.f) << 32) | ord32(0.f);
+    *reinterpret_cast<unsigned long long*>(stats + 2) = key;
+}
+void launch_stats_init(unsigned* stats, hipStream_t st) {
+    hipLaunchKernelGGL(stats_init_kernel, dim3(1), dim3(1), 0, st, stats);
+    VR_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void mag_pad_kernel(const float2* __restrict__ spec, int bins, int T,
+                                                      float* __restrict__ mag_pad, int Wpad, int pad_l,
+                                                      unsigned* stats) {
+    const long long total = 2LL * bins * T;
+    float mx = 0.f;
+    unsigned long long key = 0ull;
+    for (long long gid = (long long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long long)gridDim.x * 256) {
+        const int t = (int)(gid % T);
+        const long long row = gid / T;               // ch*bins + bin
+        const float2 z = spec[gid];
+        const float m = sqrtf(z.x * z.x + z.y * z.y);
+        mag_pad[row * Wpad + pad_l + t] = m;
+        mx = fmaxf(mx, m);
+        const unsigned long long k = ((unsigned long long)ord32(z.x) << 32) | ord32(z.y);
+        key = k > key ? k : key;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        const unsigned long long o = __shfl_xor(key, off, 64);
+        key = o > key ? o : key;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(stats, __float_as_uint(mx));
+        atomicMax(reinterpret_cast<unsigned long long*>(stats + 2), key);
+    }
+}
+
+void launch_mag_pad(const float2* spec, int bins, int T, float* mag_pad, int Wpad, int pad_l, unsigned* stats,
+                    hipStream_t st) {
+    const long long total = 2LL * bins * T;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(mag_pad_kernel, dim3(grid), dim3(256), 0, st, spec, bins, T, mag_pad, Wpad, pad_l, stats);
+    VR_HIP(hipGetLastError());
+}
+
+__global__ void coef_affine_kernel(const unsigned* stats, int mode, float* aff) {
+    float coef;
+    if (mode == 0) {
+        coef = __uint_as_float(stats[0]);
+    } else {
+        const unsigned long long key = *reinterpret_cast<const unsigned long long*>(stats + 2);
+        const float re = unord32((unsigned)(key >> 32)), im = unord32((unsigned)(key & 0xffffffffu));
+        coef = sqrtf(re * re + im * im);
+    }
+    const float s = 1.f / coef;
+    aff[0] = s; aff[1] = 0.f; aff[2] = s; aff[3] = 0.f;
+}
+void launch_coef_affine(const unsigned* stats, int mode, float* aff, hipStream_t st) {
+    hipLaunchKernelGGL(coef_affine_kernel, dim3(1), dim3(1), 0, st, stats, mode, aff);
+    VR_HIP(hipGetLastError());
+}
+
+__global__ void apply_mask_kernel(const float2* __restrict__ spec, int bins, int T, const float* __restrict__ ma,
+                                  int Wa, const float* __restrict__ mb, int Wb, int shift, float2* __restrict__ y,
+                                  float2* __restrict__ v) {
+    const long long total = 2LL * bins * T;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int t = (int)(gid % T);
+    const long long row = gid / T;
+    float m = ma[row * Wa + t];
+    if (mb) m = (m + mb[row * Wb + t + shift]) * 0.5f;
+    const float2 z = spec[gid];
+    y[gid] = make_float2(m * z.x, m * z.y);
+    const float im = 1.f - m;
+    v[gid] = make_float2(im * z.x, im * z.y);
+}
+
+void launch_apply_mask(const float2* spec, int bins, int T, const float* mask_a, int Wa, const float* mask_b, int Wb,
+                       int shift, float2* y, float2* v, hipStream_t st) {
+    const long long total = 2LL * bins * T;
+    hipLaunchKernelGGL(apply_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, spec, bins, T, mask_a,
+                       Wa, mask_b, Wb, shift, y, v);
+    VR_HIP(hipGetLastError());
+}
+
+}  // namespace vr

@@ -1,0 +1,98 @@
+// Shared declarations for libvr_mi355.so (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+namespace vr {
+
+// ---------------------------------------------------------------------------------------------
+// Error plumbing: every HIP call is checked; failures become C++ exceptions that the C ABI turns
+// into negative status codes + a thread-local message (include/vr_mi355.h).
+// ---------------------------------------------------------------------------------------------
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define VR_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            throw ::vr::Error(-3, std::string(#expr) + ": " + hipGetErrorString(_e));             \
+    } while (0)
+
+#define VR_CHECK(cond, code, msg)                                                                 \
+    do {                                                                                          \
+        if (!(cond)) throw ::vr::Error((code), (msg));                                            \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Activation tensors in HBM.
+//
+// Layout: [N, C, H, W] fp32, W (time frames) contiguous, arbitrary N/C/H strides so that band
+// splits (lib/nets.py:88-90), frequency concatenation (nets.py:93,99) and the overlapping
+// sliding-window crops (inference.py:44-48) are all *views* -- nothing is copied.
+//
+// Every conv output is stored RAW (pre-BatchNorm).  The BatchNorm affine (scale, shift per
+// channel) and the activation slope travel with the tensor and are applied by the CONSUMER when
+// it stages the tile into LDS:   value = act(raw * scale[c] + shift[c]),
+//                                act(v) = v > 0 ? v : slope * v   (0 ReLU, 0.01 LeakyReLU, 1 identity).
+// Eval mode fills (scale, shift) from running stats once; train mode fills them from batch stats
+// after the producing conv -- the conv kernels are identical in both modes, and the raw tensor is
+// exactly what BatchNorm backward needs.
+// `hsplit`: rows h < hsplit use aff0, rows >= hsplit use aff1 (aux1/aux2 hold the low-band and
+// high-band nets' outputs stacked along frequency, each with its own BatchNorm).
+// ---------------------------------------------------------------------------------------------
+struct Tensor {
+    float* p = nullptr;
+    int N = 0, C = 0, H = 0, W = 0;
+    long long sN = 0, sC = 0, sH = 0;
+    const float* aff0 = nullptr;   // [C][2] (scale, shift) on device, or null = identity
+    const float* aff1 = nullptr;
+    int hsplit = 1 << 30;
+    float slope = 1.f;
+    const float* post = nullptr;   // [N][C] post-activation multiplier (Dropout2d), or null
+};
+
+// One input of a (virtually concatenated) convolution.
+struct ConvSrc {
+    const float* p;
+    const float* aff0;
+    const float* aff1;
+    long long sN, sC, sH;
+    int C, H, W;       // source dims (BEFORE the optional x2 upsample)
+    int hsplit;
+    float slope;
+    int up;            // 1: bilinear x2, align_corners=True (lib/layers.py:52), fused into the load
+    float rh, rw;      // (H-1)/(2H-1), (W-1)/(2W-1) as torch's area_pixel_compute_scale<float>
+    const float* post; // [N][C] multiplier applied after the activation (Dropout2d keep-mask / 0.9), or null
+};
+
+struct ConvArgs {
+    ConvSrc src[3];
+    int nsrc, c1, c2;          // src0 = channels [0,c1), src1 = [c1,c2), src2 = [c2,Cin)
+    int Cin;
+    const float* w;            // [Cin][KS*KS][CoutPad]  (K-major, cout contiguous)
+    const float* bias;         // [Cout] or null
+    int Cout, CoutPad;
+    float* out;
+    long long oN, oC, oH;
+    float* part;               // per-block BatchNorm partials [npt][Cout][2] (sum, sumsq) or null
+    int N, Hout, Wout, Hin, Win;
+    int pad_h, pad_w;
+    int tiles_w, tiles_h, npt, nct;
+};
+
+struct ConvShape {             // static description used by the launcher
+    int KS, stride, dil_h, dil_w;
+};
+
+// Returns the algorithmic FLOPs of the launch (2*MACs) for roofline accounting.
+double launch_conv(const ConvArgs& a, const ConvShape& s, hipStream_t st);
+size_t conv_part_count(const ConvArgs& a, const ConvShape& s);   // #partials rows (npt)
+void conv_fill_tiling(ConvArgs& a, const ConvShape& s);
+
+}  // namespace vr

@@ -1,0 +1,230 @@
+"""CascadedNet facade with the reference's surface (lib/nets.py:44-141) over libvr_mi355.so.
+
+What callers touch and what happens here:
+
+    nets.CascadedNet(n_fft, hop_length, nout=32, nout_lstm=128)  -> host-side state (689 tensors)
+    .load_state_dict(dict) / .state_dict()                      -> reference keys / torch layouts
+    .to(device)                                                 -> creates the native handle on that GPU
+    .eval() / .train()                                          -> vr_set_mode
+    .offset, .n_fft, .hop_length, .max_bin, .output_bin         -> same attributes
+    .forward(x) / __call__(x) / .predict_mask(x) / .predict(x)  -> vr_forward (modes 0 / 1 / 2)
+
+Inputs and outputs are torch tensors; a tensor already on the handle's GPU is passed by device
+pointer (no host round trip), a CPU tensor is copied in by the library.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import native
+
+
+def _cba(spec, p, nin, nout, k):
+    spec.append((p + '.conv.0.weight', (nout, nin, k, k), 'conv'))
+    spec.append((p + '.conv.1.weight', (nout,), 'ones'))
+    spec.append((p + '.conv.1.bias', (nout,), 'zeros'))
+    spec.append((p + '.conv.1.running_mean', (nout,), 'zeros'))
+    spec.append((p + '.conv.1.running_var', (nout,), 'ones'))
+    spec.append((p + '.conv.1.num_batches_tracked', (), 'nbt'))
+
+
+def _base_net(spec, p, nin, c, nin_lstm, nout_lstm):
+    _cba(spec, p + '.enc1', nin, c, 3)
+    chans = (c, 2 * c, 4 * c, 6 * c, 8 * c)
+    for i in range(4):
+        _cba(spec, '%s.enc%d.conv1' % (p, i + 2), chans[i], chans[i + 1], 3)
+        _cba(spec, '%s.enc%d.conv2' % (p, i + 2), chans[i + 1], chans[i + 1], 3)
+    _cba(spec, p + '.aspp.conv1.1', 8 * c, 8 * c, 1)
+    _cba(spec, p + '.aspp.conv2', 8 * c, 8 * c, 1)
+    for i in (3, 4, 5):
+        _cba(spec, '%s.aspp.conv%d' % (p, i), 8 * c, 8 * c, 3)
+    _cba(spec, p + '.aspp.bottleneck', 40 * c, 8 * c, 1)
+    _cba(spec, p + '.dec4.conv1', 14 * c, 6 * c, 3)
+    _cba(spec, p + '.dec3.conv1', 10 * c, 4 * c, 3)
+    _cba(spec, p + '.dec2.conv1', 6 * c, 2 * c, 3)
+    q = p + '.lstm_dec2'
+    _cba(spec, q + '.conv', 2 * c, 1, 1)
+    hid = nout_lstm // 2
+    for sfx in ('', '_reverse'):
+        spec.append((q + '.lstm.weight_ih_l0' + sfx, (4 * hid, nin_lstm), ('uniform', 1.0 / math.sqrt(hid))))
+        spec.append((q + '.lstm.weight_hh_l0' + sfx, (4 * hid, hid), ('uniform', 1.0 / math.sqrt(hid))))
+        spec.append((q + '.lstm.bias_ih_l0' + sfx, (4 * hid,), ('uniform', 1.0 / math.sqrt(hid))))
+        spec.append((q + '.lstm.bias_hh_l0' + sfx, (4 * hid,), ('uniform', 1.0 / math.sqrt(hid))))
+    spec.append((q + '.dense.0.weight', (nin_lstm, nout_lstm), ('uniform', 1.0 / math.sqrt(nout_lstm))))
+    spec.append((q + '.dense.0.bias', (nin_lstm,), ('uniform', 1.0 / math.sqrt(nout_lstm))))
+    spec.append((q + '.dense.1.weight', (nin_lstm,), 'ones'))
+    spec.append((q + '.dense.1.bias', (nin_lstm,), 'zeros'))
+    spec.append((q + '.dense.1.running_mean', (nin_lstm,), 'zeros'))
+    spec.append((q + '.dense.1.running_var', (nin_lstm,), 'ones'))
+    spec.append((q + '.dense.1.num_batches_tracked', (), 'nbt'))
+    _cba(spec, p + '.dec1.conv1', 3 * c + 1, c, 3)
+
+
+def state_spec(n_fft, nout, nout_lstm):
+    """(key, shape, init) in the reference's registration order (lib/nets.py:59-80)."""
+    nin = 2
+    nin_lstm = (n_fft // 2) // 2
+    spec = []
+    _base_net(spec, 'stg1_low_band_net.0', nin, nout // 2, nin_lstm // 2, nout_lstm)
+    _cba(spec, 'stg1_low_band_net.1', nout // 2, nout // 4, 1)
+    _base_net(spec, 'stg1_high_band_net', nin, nout // 4, nin_lstm // 2, nout_lstm // 2)
+    _base_net(spec, 'stg2_low_band_net.0', nout // 4 + nin, nout, nin_lstm // 2, nout_lstm)
+    _cba(spec, 'stg2_low_band_net.1', nout, nout // 2, 1)
+    _base_net(spec, 'stg2_high_band_net', nout // 4 + nin, nout // 2, nin_lstm // 2, nout_lstm // 2)
+    _base_net(spec, 'stg3_full_band_net', 3 * nout // 4 + nin, nout, nin_lstm, nout_lstm)
+    spec.append(('out.weight', (nin, nout, 1, 1), 'conv'))
+    spec.append(('aux_out.weight', (nin, 3 * nout // 4, 1, 1), 'conv'))
+    return spec
+
+
+def _init_tensor(shape, init):
+    if init == 'ones':
+        return torch.ones(shape)
+    if init == 'zeros':
+        return torch.zeros(shape)
+    if init == 'nbt':
+        return torch.zeros((), dtype=torch.int64)
+    if init == 'conv':      # torch's default Conv2d init: kaiming_uniform(a=sqrt(5)) = U(+-1/sqrt(fan_in))
+        bound = 1.0 / math.sqrt(shape[1] * shape[2] * shape[3])
+        return torch.empty(shape).uniform_(-bound, bound)
+    kind, bound = init
+    assert kind == 'uniform'
+    return torch.empty(shape).uniform_(-bound, bound)
+
+
+class CascadedNet(object):
+
+    def __init__(self, n_fft, hop_length, nout=32, nout_lstm=128, is_complex=False):
+        if is_complex:
+            raise NotImplementedError('is_complex=True is unreachable from every reference caller '
+                                      '(lib/nets.py:83-84,104-107) and is not part of the MI355X hot path')
+        self.n_fft = n_fft
+        self.hop_length = hop_length
+        self.is_complex = False
+        self.nout = nout
+        self.nout_lstm = nout_lstm
+        self.max_bin = n_fft // 2
+        self.output_bin = n_fft // 2 + 1
+        self.nin_lstm = self.max_bin // 2
+        self.offset = 64
+        self.training = True
+        self._spec = state_spec(n_fft, nout, nout_lstm)
+        self._state = OrderedDict((k, _init_tensor(shape, init)) for k, shape, init in self._spec)
+        self._handle = None
+        self._device = torch.device('cpu')
+        self._host_stale = False      # device weights newer than self._state (after training steps)
+
+    # ---- nn.Module-like surface -------------------------------------------------------------------
+    def state_dict(self):
+        self._pull()
+        return OrderedDict((k, v.clone()) for k, v in self._state.items())
+
+    def load_state_dict(self, state_dict, strict=True):
+        missing = [k for k in self._state if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in self._state]
+        if strict and (missing or unexpected):
+            raise RuntimeError('Error(s) in loading state_dict for CascadedNet: missing %s unexpected %s'
+                               % (missing[:5], unexpected[:5]))
+        for k, v in state_dict.items():
+            if k not in self._state:
+                continue
+            v = torch.as_tensor(v).detach().cpu()
+            if tuple(v.shape) != tuple(self._state[k].shape):
+                raise RuntimeError('size mismatch for %s: %s vs %s' % (k, tuple(v.shape), tuple(self._state[k].shape)))
+            self._state[k] = v.to(self._state[k].dtype).contiguous().clone()
+        self._host_stale = False
+        self._push()
+        return self
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type == 'cuda':
+            index = device.index if device.index is not None else torch.cuda.current_device()
+            if self._handle is None or self._handle.device != index:
+                self._pull()
+                if self._handle is not None:
+                    self._handle.close()
+                self._handle = native.Handle(index, self.n_fft, self.hop_length, self.nout, self.nout_lstm)
+                self._device = torch.device('cuda', index)
+                self._push()
+                native.check(native.lib().vr_set_mode(self._handle.h, int(self.training)))
+        elif device.type == 'cpu':
+            self._pull()
+            if self._handle is not None:
+                self._handle.close()
+                self._handle = None
+            self._device = device
+        else:
+            raise RuntimeError('CascadedNet (MI355X-native) supports cuda devices only, got %s' % device)
+        return self
+
+    def cuda(self, index=None):
+        return self.to(torch.device('cuda', index if index is not None else 0))
+
+    def train(self, mode=True):
+        self.training = bool(mode)
+        if self._handle is not None:
+            native.check(native.lib().vr_set_mode(self._handle.h, int(self.training)))
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    # ---- compute ------------------------------------------------------------------------------------
+    def _need_handle(self):
+        if self._handle is None:
+            raise RuntimeError('CascadedNet has no MI355X handle: call .to(torch.device("cuda:N")) first '
+                               '(this package has no CPU fallback)')
+        return self._handle
+
+    def _run(self, x, mode):
+        h = self._need_handle()
+        if not torch.is_tensor(x):
+            x = torch.as_tensor(x)
+        if x.is_complex():
+            raise NotImplementedError('is_complex inputs are not supported (pass torch.abs(X))')
+        if x.dim() != 4 or x.shape[1] != 2 or x.shape[2] != self.output_bin:
+            raise ValueError('expected input [B, 2, %d, T], got %s' % (self.output_bin, tuple(x.shape)))
+        B, T = int(x.shape[0]), int(x.shape[3])
+        Wm = T if mode == 0 else T - 2 * self.offset
+        on_dev = x.is_cuda
+        if on_dev and x.device.index != h.device:
+            raise RuntimeError('input is on %s but the model is on cuda:%d' % (x.device, h.device))
+        x = x.detach().to(torch.float32).contiguous()
+        out = torch.empty((B, 2, self.output_bin, max(Wm, 0)), dtype=torch.float32,
+                          device=x.device if on_dev else 'cpu')
+        if on_dev:
+            torch.cuda.current_stream(x.device).synchronize()
+        native.check(native.lib().vr_forward(h.h, x.data_ptr(), int(on_dev), B, T, mode, out.data_ptr(), int(on_dev)))
+        return out
+
+    def forward(self, x):
+        """CascadedNet.forward (lib/nets.py:82-117): mask [B,2,n_fft/2+1,T]."""
+        return self._run(x, 0)
+
+    __call__ = forward
+
+    def predict_mask(self, x):
+        """CascadedNet.predict_mask (lib/nets.py:124-131): mask[..., 64:-64]."""
+        return self._run(x, 1)
+
+    def predict(self, x):
+        """CascadedNet.predict (lib/nets.py:133-141): (x * mask)[..., 64:-64]."""
+        return self._run(x, 2)
+
+    # ---- host <-> device weights ----------------------------------------------------------------------
+    def _push(self):
+        if self._handle is None:
+            return
+        for k, v in self._state.items():
+            self._handle.set_param(k, v.numpy())
+
+    def _pull(self):
+        if self._handle is None or not (self._host_stale or self.training):
+            return
+        for k, shape, init in self._spec:
+            arr = self._handle.get_param(k, shape, init == 'nbt')
+            self._state[k] = torch.from_numpy(np.array(arr)).reshape(shape)
+        self._host_stale = False
