@@ -89,6 +89,9 @@ def main():
     ap.add_argument('--train-batch', type=int, default=16)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
+    if os.environ.get('VR_BENCH_WATCHDOG'):
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['VR_BENCH_WATCHDOG']), exit=True)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))

@@ -125,7 +125,7 @@ class Handle:
         return out
 
     def set_param(self, key, arr):
-        arr = np.ascontiguousarray(arr)
+        arr = np.require(arr, requirements=['C'])      # (ascontiguousarray would turn 0-d into 1-d)
         shape = (ctypes.c_int64 * max(arr.ndim, 1))(*arr.shape)
         check(lib().vr_set_param(self.h, key.encode(), np_ptr(arr), shape, arr.ndim))
 

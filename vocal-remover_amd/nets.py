@@ -193,7 +193,7 @@ class CascadedNet(object):
         if on_dev and x.device.index != h.device:
             raise RuntimeError('input is on %s but the model is on cuda:%d' % (x.device, h.device))
         x = x.detach().to(torch.float32).contiguous()
-        out = torch.empty((B, 2, self.output_bin, max(Wm, 0)), dtype=torch.float32,
+        out = torch.empty((B, 2, self.output_bin, max(Wm, 1)), dtype=torch.float32,   # Wm <= 0 -> native raises
                           device=x.device if on_dev else 'cpu')
         if on_dev:
             torch.cuda.current_stream(x.device).synchronize()
