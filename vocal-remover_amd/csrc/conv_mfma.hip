@@ -26,41 +26,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float act_apply(float v, float slope) { return v > 0.f ? v : v * slope; }
 
-// Fetch one element of source `s` at virtual-input coordinate (hi, wi), channel cl, image n,
-// applying the pending BatchNorm affine + activation (and the bilinear x2 upsample if s.up).
-__device__ __forceinline__ float fetch_src(const ConvSrc& s, int n, int cl, int hi, int wi) {
-    const float* base = s.p + (long long)n * s.sN + (long long)cl * s.sC;
-    if (!s.up) {
-        float raw = base[(long long)hi * s.sH + wi];
-        const float* aff = (hi < s.hsplit) ? s.aff0 : s.aff1;
-        float sc = 1.f, sh = 0.f;
-        if (aff) { sc = aff[2 * cl]; sh = aff[2 * cl + 1]; }
-        float v = act_apply(fmaf(raw, sc, sh), s.slope);
-        if (s.post) v *= s.post[n * s.C + cl];
-        return v;
-    }
-    // torch upsample_bilinear2d, align_corners=True: src = dst * (in-1)/(out-1)
-    float h1r = s.rh * (float)hi;
-    int h1 = (int)h1r;
-    int h1p = (h1 < s.H - 1) ? 1 : 0;
-    float h1l = h1r - (float)h1, h0l = 1.f - h1l;
-    float w1r = s.rw * (float)wi;
-    int w1 = (int)w1r;
-    int w1p = (w1 < s.W - 1) ? 1 : 0;
-    float w1l = w1r - (float)w1, w0l = 1.f - w1l;
-    float sc = 1.f, sh = 0.f;
-    if (s.aff0) { sc = s.aff0[2 * cl]; sh = s.aff0[2 * cl + 1]; }
-    const float* r0 = base + (long long)h1 * s.sH + w1;
-    const float* r1 = r0 + (long long)h1p * s.sH;
-    float v00 = act_apply(fmaf(r0[0], sc, sh), s.slope);
-    float v01 = act_apply(fmaf(r0[w1p], sc, sh), s.slope);
-    float v10 = act_apply(fmaf(r1[0], sc, sh), s.slope);
-    float v11 = act_apply(fmaf(r1[w1p], sc, sh), s.slope);
-    float v = h0l * (w0l * v00 + w1l * v01) + h1l * (w0l * v10 + w1l * v11);
-    if (s.post) v *= s.post[n * s.C + cl];
-    return v;
-}
-
 template <int KS, int S, int DH, int DW, int MT, int TH, int TW, int CK, int WAVES_M>
 struct ConvCfg {
     static constexpr int KK = KS * KS;
@@ -138,37 +103,118 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     for (int c0 = 0; c0 < a.Cin; c0 += CK) {
         __syncthreads();   // previous chunk's MFMA reads are done
         // ---------------- stage weights: Ws[tap][cl][m] <- w[(c0+cl)][tap][co0+m] -------------
+        // All loads of a batch are issued before any is consumed (addresses are clamped so the
+        // loads are unconditional): one HBM/L2 round trip per batch instead of one per element.
         {
             constexpr int M4 = MT / 4;
-            for (int idx = tid; idx < CK * KK * M4; idx += 256) {
+            constexpr int NW = CK * KK * M4;
+            constexpr int WP = (NW + 255) / 256;
+            float4 wv[WP];
+#pragma unroll
+            for (int j = 0; j < WP; ++j) {
+                int idx = tid + j * 256;
+                idx = idx < NW ? idx : NW - 1;
                 const int m4 = idx % M4;
                 const int t2 = idx / M4;
                 const int tap = t2 % KK;
-                const int cl = t2 / KK;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c0 + cl < a.Cin)
-                    v = *reinterpret_cast<const float4*>(
-                        a.w + ((long long)(c0 + cl) * KK + tap) * a.CoutPad + co0 + m4 * 4);
-                *reinterpret_cast<float4*>(Ws + (tap * CK + cl) * MT + m4 * 4) = v;
+                int ci = c0 + t2 / KK;
+                ci = ci < a.Cin ? ci : a.Cin - 1;
+                wv[j] = *reinterpret_cast<const float4*>(a.w + ((long long)ci * KK + tap) * a.CoutPad + co0 + m4 * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < WP; ++j) {
+                const int idx = tid + j * 256;
+                if (idx < NW) {
+                    const int m4 = idx % M4;
+                    const int t2 = idx / M4;
+                    const int tap = t2 % KK;
+                    const int cl = t2 / KK;
+                    const float4 v = (c0 + cl < a.Cin) ? wv[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(Ws + (tap * CK + cl) * MT + m4 * 4) = v;
+                }
             }
         }
         // ---------------- stage input: one channel per wave pass, lanes over the haloed tile ----
+#pragma unroll 1
         for (int cl = wave; cl < CK; cl += 4) {
             const int ci = c0 + cl;               // wave-uniform
             float* dst = Xs + cl * TH_in * TWp;
+            constexpr int NE = TH_in * TW_in;
+            constexpr int NP = (NE + 63) / 64;
             if (ci >= a.Cin) {
-                for (int e = lane; e < TH_in * TW_in; e += 64) dst[(e / TW_in) * TWp + (e % TW_in)] = 0.f;
+                for (int e = lane; e < NE; e += 64) dst[(e / TW_in) * TWp + (e % TW_in)] = 0.f;
                 continue;
             }
             const int si = (ci >= a.c1) + (ci >= a.c2);
             const ConvSrc& s = a.src[si];
             const int clc = ci - (si == 0 ? 0 : (si == 1 ? a.c1 : a.c2));
-            for (int e = lane; e < TH_in * TW_in; e += 64) {
-                const int hh = e / TW_in, ww = e % TW_in;
-                const int hi = hbase + hh, wi = wbase + ww;
-                float v = 0.f;
-                if (hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win) v = fetch_src(s, n, clc, hi, wi);
-                dst[hh * TWp + ww] = v;
+            const float* base = s.p + (long long)n * s.sN + (long long)clc * s.sC;
+            float sc0 = 1.f, sh0 = 0.f, sc1 = 1.f, sh1 = 0.f;
+            if (s.aff0) { sc0 = s.aff0[2 * clc]; sh0 = s.aff0[2 * clc + 1]; }
+            if (s.aff1) { sc1 = s.aff1[2 * clc]; sh1 = s.aff1[2 * clc + 1]; }
+            const float post = s.post ? s.post[n * s.C + clc] : 1.f;
+            const float slope = s.slope;
+            if (!s.up) {
+                constexpr int PB = NP < 6 ? NP : 6;
+#pragma unroll 1
+                for (int p0 = 0; p0 < NP; p0 += PB) {
+                    float raw[PB];
+#pragma unroll
+                    for (int j = 0; j < PB; ++j) {
+                        int e = lane + (p0 + j) * 64;
+                        e = e < NE ? e : NE - 1;
+                        int hi = hbase + e / TW_in, wi = wbase + e % TW_in;
+                        hi = hi < 0 ? 0 : (hi >= a.Hin ? a.Hin - 1 : hi);
+                        wi = wi < 0 ? 0 : (wi >= a.Win ? a.Win - 1 : wi);
+                        raw[j] = base[(long long)hi * s.sH + wi];
+                    }
+#pragma unroll
+                    for (int j = 0; j < PB; ++j) {
+                        const int e = lane + (p0 + j) * 64;
+                        const int hh = e / TW_in, ww = e % TW_in;
+                        const int hi = hbase + hh, wi = wbase + ww;
+                        const bool lo = hi < s.hsplit;
+                        float v = act_apply(fmaf(raw[j], lo ? sc0 : sc1, lo ? sh0 : sh1), slope) * post;
+                        if (!(hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win)) v = 0.f;
+                        if (e < NE) dst[hh * TWp + ww] = v;
+                    }
+                }
+            } else {
+                // bilinear x2, align_corners=True (torch upsample_bilinear2d): src = dst*(in-1)/(out-1)
+                constexpr int PB = NP < 3 ? NP : 3;
+#pragma unroll 1
+                for (int p0 = 0; p0 < NP; p0 += PB) {
+                    float r00[PB], r01[PB], r10[PB], r11[PB];
+#pragma unroll
+                    for (int j = 0; j < PB; ++j) {
+                        int e = lane + (p0 + j) * 64;
+                        e = e < NE ? e : NE - 1;
+                        int hi = hbase + e / TW_in, wi = wbase + e % TW_in;
+                        hi = hi < 0 ? 0 : (hi >= a.Hin ? a.Hin - 1 : hi);
+                        wi = wi < 0 ? 0 : (wi >= a.Win ? a.Win - 1 : wi);
+                        const int h1 = (int)(s.rh * (float)hi), w1 = (int)(s.rw * (float)wi);
+                        const int h1p = (h1 < s.H - 1) ? 1 : 0, w1p = (w1 < s.W - 1) ? 1 : 0;
+                        const float* q0 = base + (long long)h1 * s.sH + w1;
+                        const float* q1 = q0 + (long long)h1p * s.sH;
+                        r00[j] = q0[0]; r01[j] = q0[w1p]; r10[j] = q1[0]; r11[j] = q1[w1p];
+                    }
+#pragma unroll
+                    for (int j = 0; j < PB; ++j) {
+                        const int e = lane + (p0 + j) * 64;
+                        const int hh = e / TW_in, ww = e % TW_in;
+                        const int hi = hbase + hh, wi = wbase + ww;
+                        const float h1r = s.rh * (float)hi, w1r = s.rw * (float)wi;
+                        const float h1l = h1r - (float)(int)h1r, w1l = w1r - (float)(int)w1r;
+                        const float h0l = 1.f - h1l, w0l = 1.f - w1l;
+                        const float v00 = act_apply(fmaf(r00[j], sc0, sh0), slope);
+                        const float v01 = act_apply(fmaf(r01[j], sc0, sh0), slope);
+                        const float v10 = act_apply(fmaf(r10[j], sc0, sh0), slope);
+                        const float v11 = act_apply(fmaf(r11[j], sc0, sh0), slope);
+                        float v = (h0l * (w0l * v00 + w1l * v01) + h1l * (w0l * v10 + w1l * v11)) * post;
+                        if (!(hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win)) v = 0.f;
+                        if (e < NE) dst[hh * TWp + ww] = v;
+                    }
+                }
             }
         }
         __syncthreads();
