@@ -82,6 +82,26 @@ int vr_separate(vr_handle h, const float* spec, int spec_on_device, int T, int t
 int vr_separate_wave(vr_handle h, const float* wave, int wave_on_device, int64_t L, int tta, int batchsize,
                      int cropsize, float* y_wave, float* v_wave, int out_on_device);
 
+/* ---- training: the body of train.train_epoch (train.py:77-96) ------------------------------------ */
+/* mask = model(X); loss = L1Loss()(mask * X, y); (loss / accumulation_steps).backward()
+ * X, y: [B, 2, bins, T] fp32.  Gradients ACCUMULATE in the library's gradient arena until vr_zero_grad
+ * (model.zero_grad()).  *loss_out = the un-scaled mean L1 loss (loss.item()).  mask_out (optional,
+ * may be NULL): the full-width mask [B,2,bins,T] that model(X) returns.  Needs vr_set_mode(h, 1).    */
+int vr_train_step(vr_handle h, const float* X, const float* y, int on_device, int B, int T, int accumulation_steps,
+                  float* loss_out, float* mask_out, int mask_on_device);
+/* torch.optim.Adam(lr, betas=(b1,b2), eps, weight_decay=0).step()   train.py:215-218,95
+ * grad_scale multiplies every gradient first (1/world_size after a SUM all-reduce).                */
+int vr_adam_step(vr_handle h, float lr, float b1, float b2, float eps, float grad_scale);
+int vr_zero_grad(vr_handle h);                                          /* model.zero_grad(), train.py:96 */
+int vr_get_grad(vr_handle h, const char* key, float* host, int64_t capacity_bytes);   /* param.grad, torch layout */
+/* nn.Dropout2d(0.1) on the five ASPP outputs (lib/layers.py:90).  mode 0: off; 1: library RNG (seed);
+ * 2: injected keep-masks [5][B][8*nout] holding 0 or 1/0.9 (parity tests), nets in the order
+ * stg1_low, stg1_high, stg2_low, stg2_high, stg3_full, row pitch 8*c of each net.                   */
+int vr_set_dropout(vr_handle h, int mode, uint64_t seed, const float* masks, int B);
+/* The single flat fp32 gradient bucket (device pointer + element count) for the data-parallel
+ * all-reduce (RCCL through torch.distributed): all-reduce it in place, then vr_adam_step.           */
+int vr_grad_arena(vr_handle h, float** device_ptr, int64_t* numel);
+
 /* ---- measurement hooks (bench.py) ----------------------------------------------------------- */
 /* Bracket subsequent calls: every MFMA-conv launch is timed with HIP events on the handle's stream. */
 int vr_profile_begin(vr_handle h);
@@ -94,6 +114,12 @@ int vr_profile_end(vr_handle h, double* conv_ms, double* conv_flops, int* conv_l
 int vr_debug_conv2d(vr_handle h, const float* x, int N, int Cin, int H, int W, const float* w, int Cout,
                     int ksize, int stride, int dil_h, int dil_w, int upsample, const float* affine,
                     float slope, const float* bias, float* out, float* stats_out);
+/* Backward of the same single convolution through the MFMA data-gradient / weight-gradient kernels:
+ * dz [N,Cout,Hout,Wout] -> dx_out [N,Cin,H,W] (gradient w.r.t. the activated, pre-upsample input
+ * values) and dw_out (OIHW).                                                                       */
+int vr_debug_conv2d_backward(vr_handle h, const float* x, int N, int Cin, int H, int W, const float* w, int Cout,
+                             int ksize, int stride, int dil_h, int dil_w, int upsample, const float* affine,
+                             float slope, const float* dz, float* dx_out, float* dw_out);
 /* Record intermediate activations of the next vr_forward and read them back (post-activation). */
 int vr_debug_record_taps(vr_handle h, int enable);
 int64_t vr_debug_get_tap(vr_handle h, const char* name, float* host, int64_t capacity_floats, int64_t* shape4);

@@ -148,6 +148,46 @@ int vr_separate_wave(vr_handle h, const float* wave, int wave_on_device, int64_t
     });
 }
 
+int vr_train_step(vr_handle h, const float* X, const float* y, int on_device, int B, int T, int accumulation_steps,
+                  float* loss_out, float* mask_out, int mask_on_device) {
+    NEED(h);
+    return guard([&] {
+        VR_CHECK(X && y, VR_ERR_BAD_ARGUMENT, "null argument");
+        h->m.train_fwd_bwd_api(X, y, on_device != 0, B, T, accumulation_steps, loss_out, mask_out, mask_on_device != 0);
+    });
+}
+
+int vr_adam_step(vr_handle h, float lr, float b1, float b2, float eps, float grad_scale) {
+    NEED(h);
+    return guard([&] { h->m.adam_step_api(lr, b1, b2, eps, grad_scale); });
+}
+
+int vr_zero_grad(vr_handle h) {
+    NEED(h);
+    return guard([&] { h->m.zero_grad_api(); });
+}
+
+int vr_get_grad(vr_handle h, const char* key, float* host, int64_t capacity_bytes) {
+    NEED(h);
+    return guard([&] {
+        VR_CHECK(key && host, VR_ERR_BAD_ARGUMENT, "null argument");
+        h->m.get_grad(key, host, capacity_bytes);
+    });
+}
+
+int vr_set_dropout(vr_handle h, int mode, uint64_t seed, const float* masks, int B) {
+    NEED(h);
+    return guard([&] { h->m.set_dropout(mode, seed, masks, B); });
+}
+
+int vr_grad_arena(vr_handle h, float** device_ptr, int64_t* numel) {
+    NEED(h);
+    return guard([&] {
+        VR_CHECK(device_ptr && numel, VR_ERR_BAD_ARGUMENT, "null argument");
+        h->m.grad_arena(device_ptr, numel);
+    });
+}
+
 int vr_profile_begin(vr_handle h) {
     NEED(h);
     return guard([&] { h->m.profile_begin(); });
@@ -165,6 +205,16 @@ int vr_debug_conv2d(vr_handle h, const float* x, int N, int Cin, int H, int W, c
     return guard([&] {
         VR_CHECK(x && w && out, VR_ERR_BAD_ARGUMENT, "null argument");
         h->m.debug_conv(x, N, Cin, H, W, w, Cout, ksize, stride, dil_h, dil_w, upsample, affine, slope, bias, out, stats_out);
+    });
+}
+
+int vr_debug_conv2d_backward(vr_handle h, const float* x, int N, int Cin, int H, int W, const float* w, int Cout,
+                             int ksize, int stride, int dil_h, int dil_w, int upsample, const float* affine, float slope,
+                             const float* dz, float* dx_out, float* dw_out) {
+    NEED(h);
+    return guard([&] {
+        VR_CHECK(x && w && dz && dx_out && dw_out, VR_ERR_BAD_ARGUMENT, "null argument");
+        h->m.debug_conv_bwd(x, N, Cin, H, W, w, Cout, ksize, stride, dil_h, dil_w, upsample, affine, slope, dz, dx_out, dw_out);
     });
 }
 

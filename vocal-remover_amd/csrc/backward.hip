@@ -1,0 +1,449 @@
+// Backward-pass kernels around the MFMA dgrad / wgrad launches (train.py:91-96 of the reference:
+// loss.backward(); optimizer.step()).  All HBM-bound streaming / reduction kernels.
+//
+// Gradient convention: for every activation tensor T the buffer G_T holds dLoss/d(value consumers
+// see) = gradient w.r.t. post-BatchNorm, post-activation, post-dropout values.  The producer's
+// BatchNorm backward turns G_T (in place) into dz, the gradient at the RAW conv output:
+//     dy = G * post * act'(y),  y = z*scale + shift
+//     dz = scale * (dy - mean(dy) - xhat * mean(dy*xhat))  =  kA*dy + kB*z + kC      (per channel)
+#include "kernels.h"
+
+namespace vr {
+
+__device__ __forceinline__ float dact(float y, float slope) { return y > 0.f ? 1.f : slope; }
+
+// ---------------------------------------------------------------------------------------------------
+// BatchNorm backward, pass 1: per-channel partial sums S1 = sum dy, S2 = sum dy*z.
+// grid = (chunks of N*H rows, C).  part[(chunk*C + c)*2 + {0,1}]
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
+    const int c = blockIdx.y;
+    const int rows = a.N * a.H;
+    const int r0 = (int)((long long)blockIdx.x * rows / gridDim.x), r1 = (int)((long long)(blockIdx.x + 1) * rows / gridDim.x);
+    const float sc = a.aff ? a.aff[2 * (a.aff_bcast ? 0 : c)] : 1.f, sh = a.aff ? a.aff[2 * (a.aff_bcast ? 0 : c) + 1] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    const int total = (r1 - r0) * a.W;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int r = r0 + e / a.W, w = e % a.W;
+        const int n = r / a.H, h = r % a.H;
+        const long long off = (long long)n * a.sN + (long long)c * a.sC + (long long)h * a.sH + w;
+        const float z = a.z[off];
+        float g = a.g[off];
+        if (a.post) g *= a.post[n * a.C + c];
+        const float dy = g * dact(fmaf(z, sc, sh), a.slope);
+        s1 += dy;
+        s2 = fmaf(dy, z, s2);
+    }
+    __shared__ float red[8];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wave * 2] = s1; red[wave * 2 + 1] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.part[((long long)blockIdx.x * a.C + c) * 2 + 0] = red[0] + red[2] + red[4] + red[6];
+        a.part[((long long)blockIdx.x * a.C + c) * 2 + 1] = red[1] + red[3] + red[5] + red[7];
+    }
+}
+
+// pass 1b: finalize -> d(gamma), d(beta) into the gradient arena, coefficients (kA,kB,kC) for pass 2
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdArgs a, int nchunks) {
+    const int c = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < nchunks; i += 256) {
+        s1 += (double)a.part[((long long)i * a.C + c) * 2 + 0];
+        s2 += (double)a.part[((long long)i * a.C + c) * 2 + 1];
+    }
+    __shared__ double r1[256], r2[256];
+    r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) { r1[threadIdx.x] += r1[threadIdx.x + off]; r2[threadIdx.x] += r2[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double M = (double)a.N * a.H * a.W;
+        const double mean = a.save_mean[c], invstd = a.save_invstd[c];
+        const double dbeta = r1[0];
+        const double dgamma = invstd * (r2[0] - mean * r1[0]);
+        const double scale = (double)a.gamma[c] * invstd;
+        if (a.acc_grads) { a.dgamma[c] += (float)dgamma; a.dbeta[c] += (float)dbeta; }
+        else { a.dgamma[c] = (float)dgamma; a.dbeta[c] = (float)dbeta; }
+        a.coef[3 * c + 0] = (float)scale;
+        a.coef[3 * c + 1] = (float)(-scale * invstd * dgamma / M);
+        a.coef[3 * c + 2] = (float)(-scale * dbeta / M + scale * invstd * mean * dgamma / M);
+    }
+}
+
+// pass 2: G <- dz in place.  coef == null: no BatchNorm (dz = dy).
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
+    const long long total = (long long)a.N * a.C * a.H * a.W;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int w = (int)(gid % a.W);
+    long long t = gid / a.W;
+    const int h = (int)(t % a.H); t /= a.H;
+    const int c = (int)(t % a.C);
+    const int n = (int)(t / a.C);
+    const long long off = (long long)n * a.sN + (long long)c * a.sC + (long long)h * a.sH + w;
+    const int ca = a.aff_bcast ? 0 : c;
+    const float sc = a.aff ? a.aff[2 * ca] : 1.f, sh = a.aff ? a.aff[2 * ca + 1] : 0.f;
+    const float z = a.z[off];
+    float g = a.g[off];
+    if (a.post) g *= a.post[n * a.C + c];
+    const float dy = g * dact(fmaf(z, sc, sh), a.slope);
+    a.g[off] = a.coef ? fmaf(a.coef[3 * c], dy, fmaf(a.coef[3 * c + 1], z, a.coef[3 * c + 2])) : dy;
+}
+
+int bn_bwd_chunks(const BnBwdArgs& a) {
+    const long long per_c = (long long)a.N * a.H * a.W;
+    long long ch = per_c / 16384;
+    if (ch < 1) ch = 1;
+    if (ch > 256) ch = 256;
+    if (ch > (long long)a.N * a.H) ch = (long long)a.N * a.H;
+    return (int)ch;
+}
+
+void launch_bn_bwd(const BnBwdArgs& a, hipStream_t st) {
+    if (a.coef) {
+        const int nch = bn_bwd_chunks(a);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nch, a.C), dim3(256), 0, st, a);
+        VR_HIP(hipGetLastError());
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(a.C), dim3(256), 0, st, a, nch);
+        VR_HIP(hipGetLastError());
+    }
+    const long long total = (long long)a.N * a.C * a.H * a.W;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+    VR_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Transposed bilinear x2 (align_corners=True): G_lo += U^T D_hi, gather form (no atomics).
+// ---------------------------------------------------------------------------------------------------
+__global__ void upsample_bwd_kernel(const float* __restrict__ dhi, int N, int C, int H, int W, float rh, float rw,
+                                    float* __restrict__ glo, long long gN, long long gC, long long gH) {
+    const long long total = (long long)N * C * H * W;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int j = (int)(gid % W);
+    long long t = gid / W;
+    const int i = (int)(t % H); t /= H;
+    const int c = (int)(t % C);
+    const int n = (int)(t / C);
+    const int H2 = 2 * H, W2 = 2 * W;
+    const float* src = dhi + ((long long)n * C + c) * H2 * W2;
+    int hlo = 2 * i - 3, hhi = 2 * i + 3, wlo = 2 * j - 3, whi = 2 * j + 3;
+    hlo = hlo < 0 ? 0 : hlo; wlo = wlo < 0 ? 0 : wlo;
+    hhi = hhi > H2 - 1 ? H2 - 1 : hhi; whi = whi > W2 - 1 ? W2 - 1 : whi;
+    float acc = 0.f;
+    for (int h = hlo; h <= hhi; ++h) {
+        const float h1r = rh * (float)h;
+        const int h1 = (int)h1r;
+        const int h1p = (h1 < H - 1) ? 1 : 0;
+        const float l1 = h1r - (float)h1, l0 = 1.f - l1;
+        float wh = 0.f;
+        if (h1 == i) wh += l0;
+        if (h1 + h1p == i) wh += l1;
+        if (wh == 0.f) continue;
+        for (int w = wlo; w <= whi; ++w) {
+            const float w1r = rw * (float)w;
+            const int w1 = (int)w1r;
+            const int w1p = (w1 < W - 1) ? 1 : 0;
+            const float m1 = w1r - (float)w1, m0 = 1.f - m1;
+            float ww = 0.f;
+            if (w1 == j) ww += m0;
+            if (w1 + w1p == j) ww += m1;
+            if (ww != 0.f) acc = fmaf(wh * ww, src[(long long)h * W2 + w], acc);
+        }
+    }
+    glo[(long long)n * gN + (long long)c * gC + (long long)i * gH + j] += acc;
+}
+
+void launch_upsample_bwd(const float* dhi, int N, int C, int H, int W, float* glo, long long gN, long long gC,
+                         long long gH, hipStream_t st) {
+    const long long total = (long long)N * C * H * W;
+    const float rh = (float)(H - 1) / (float)(2 * H - 1), rw = (float)(W - 1) / (float)(2 * W - 1);
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dhi, N, C, H, W, rh, rw,
+                       glo, gN, gC, gH);
+    VR_HIP(hipGetLastError());
+}
+
+// out[n][c][w] += sum_h d[n][c][h][w]     (backward of the broadcast along H, lib/layers.py:94)
+__global__ void sum_h_kernel(const float* __restrict__ d, int N, int C, int H, int W, float* __restrict__ out) {
+    const int total = N * C * W;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int w = gid % W;
+    const int nc = gid / W;
+    const float* p = d + (long long)nc * H * W + w;
+    float s = 0.f;
+    for (int h = 0; h < H; ++h) s += p[(long long)h * W];
+    out[gid] += s;
+}
+void launch_sum_h(const float* d, int N, int C, int H, int W, float* out, hipStream_t st) {
+    const int total = N * C * W;
+    hipLaunchKernelGGL(sum_h_kernel, dim3((total + 255) / 256), dim3(256), 0, st, d, N, C, H, W, out);
+    VR_HIP(hipGetLastError());
+}
+
+// g[n][c][h][w] += gp[n][c][w] / H     (backward of AdaptiveAvgPool2d((1,None)), lib/layers.py:72)
+__global__ void avgpool_bwd_kernel(const float* __restrict__ gp, float* __restrict__ g, int N, int C, int H, int W,
+                                   long long sN, long long sC, long long sH) {
+    const long long total = (long long)N * C * H * W;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int w = (int)(gid % W);
+    long long t = gid / W;
+    const int h = (int)(t % H); t /= H;
+    const int c = (int)(t % C);
+    const int n = (int)(t / C);
+    g[(long long)n * sN + (long long)c * sC + (long long)h * sH + w] += gp[((long long)n * C + c) * W + w] / (float)H;
+}
+void launch_avgpool_bwd(const float* gp, float* g, int N, int C, int H, int W, long long sN, long long sC, long long sH,
+                        hipStream_t st) {
+    const long long total = (long long)N * C * H * W;
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gp, g, N, C, H, W, sN,
+                       sC, sH);
+    VR_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Thin convs (Cout = CO in {1,2}) backward.
+//   dgrad: G_x[n][c][h][w] (+)= post-chain is the producer's job; here  sum_o W[o][c] * dz[n][o][h][w]
+//   wgrad: dW[o][c] = sum_{n,h,w} dz[n][o][h][w] * act(x)[n][c][h][w]   (8 channels per blockIdx.y)
+// dz is dense [N][CO][H][W].
+// ---------------------------------------------------------------------------------------------------
+template <int CO>
+__global__ __launch_bounds__(256) void thin_dgrad_kernel(Tensor x, const float* __restrict__ w, const float* __restrict__ dz,
+                                                         float* __restrict__ g, int accumulate) {
+    const long long total = (long long)x.N * x.C * x.H * x.W;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int wq = (int)(gid % x.W);
+    long long t = gid / x.W;
+    const int h = (int)(t % x.H); t /= x.H;
+    const int c = (int)(t % x.C);
+    const int n = (int)(t / x.C);
+    float v = 0.f;
+#pragma unroll
+    for (int o = 0; o < CO; ++o) v = fmaf(w[o * x.C + c], dz[(((long long)n * CO + o) * x.H + h) * x.W + wq], v);
+    float* q = g + (long long)n * x.sN + (long long)c * x.sC + (long long)h * x.sH + wq;
+    *q = accumulate ? *q + v : v;
+}
+
+template <int CO>
+__global__ __launch_bounds__(256) void thin_wgrad_kernel(Tensor x, const float* __restrict__ dz, float* __restrict__ part) {
+    const int c0 = blockIdx.y * 8;
+    float acc[CO][8];
+#pragma unroll
+    for (int o = 0; o < CO; ++o)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[o][k] = 0.f;
+    const long long total = (long long)x.N * x.H * x.W;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int wq = (int)(e % x.W);
+        long long t = e / x.W;
+        const int h = (int)(t % x.H);
+        const int n = (int)(t / x.H);
+        float d[CO];
+#pragma unroll
+        for (int o = 0; o < CO; ++o) d[o] = dz[(((long long)n * CO + o) * x.H + h) * x.W + wq];
+        const float* aff = (h < x.hsplit) ? x.aff0 : x.aff1;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = c0 + k;
+            if (c < x.C) {
+                float sc = 1.f, sh = 0.f;
+                if (aff) { sc = aff[2 * c]; sh = aff[2 * c + 1]; }
+                float v = fmaf(x.p[(long long)n * x.sN + (long long)c * x.sC + (long long)h * x.sH + wq], sc, sh);
+                v = v > 0.f ? v : v * x.slope;
+                if (x.post) v *= x.post[n * x.C + c];
+#pragma unroll
+                for (int o = 0; o < CO; ++o) acc[o][k] = fmaf(d[o], v, acc[o][k]);
+            }
+        }
+    }
+    __shared__ float red[4][CO * 8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 0; o < CO; ++o)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v = acc[o][k];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == 0) red[wave][o * 8 + k] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < CO * 8) {
+        const int o = threadIdx.x / 8, k = threadIdx.x % 8;
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (c0 + k < x.C) part[(long long)blockIdx.x * CO * x.C + o * x.C + c0 + k] = v;
+    }
+}
+
+__global__ void reduce_rows_kernel(const float* __restrict__ part, long long stride, int P, float* __restrict__ out,
+                                   long long n, int accumulate, float scale) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int p = 0; p < P; ++p) s += (double)part[p * stride + i];
+    const float v = (float)s * scale;
+    out[i] = accumulate ? out[i] + v : v;
+}
+void launch_reduce_rows(const float* part, long long stride, int P, float* out, long long n, int accumulate, float scale,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, stride, P, out, n,
+                       accumulate, scale);
+    VR_HIP(hipGetLastError());
+}
+
+void launch_thin_dgrad(const Tensor& x, int CO, const float* w, const float* dz, float* g, int accumulate, hipStream_t st) {
+    const long long total = (long long)x.N * x.C * x.H * x.W;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (CO == 1) hipLaunchKernelGGL((thin_dgrad_kernel<1>), dim3(grid), dim3(256), 0, st, x, w, dz, g, accumulate);
+    else hipLaunchKernelGGL((thin_dgrad_kernel<2>), dim3(grid), dim3(256), 0, st, x, w, dz, g, accumulate);
+    VR_HIP(hipGetLastError());
+}
+
+int thin_wgrad_blocks(const Tensor& x) {
+    const long long total = (long long)x.N * x.H * x.W;
+    long long b = (total + 256 * 32 - 1) / (256 * 32);
+    if (b < 1) b = 1;
+    if (b > 1024) b = 1024;
+    return (int)b;
+}
+void launch_thin_wgrad(const Tensor& x, int CO, const float* dz, float* part, float* dw, int accumulate, hipStream_t st) {
+    const int nb = thin_wgrad_blocks(x);
+    const dim3 grid(nb, (x.C + 7) / 8);
+    if (CO == 1) hipLaunchKernelGGL((thin_wgrad_kernel<1>), grid, dim3(256), 0, st, x, dz, part);
+    else hipLaunchKernelGGL((thin_wgrad_kernel<2>), grid, dim3(256), 0, st, x, dz, part);
+    VR_HIP(hipGetLastError());
+    launch_reduce_rows(part, (long long)CO * x.C, nb, dw, (long long)CO * x.C, accumulate, 1.f, st);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Head + loss (train.py:81,89): mask = sigmoid(out(f3)) (replicate-padded row), loss = mean|mask*X - y|.
+// Writes dlogit [N][2][H][W] = dLoss/d(pre-sigmoid) * gscale and per-block |.| sums.
+// X, y: [N][2][bins][T] dense; bins = H + pad_rows.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_loss_kernel(Tensor x, const float* __restrict__ w, const float* __restrict__ X,
+                                                        const float* __restrict__ Y, int bins, float gscale,
+                                                        float* __restrict__ dlogit, float* __restrict__ mask_out,
+                                                        float* __restrict__ loss_part) {
+    const long long total = (long long)x.N * x.H * x.W;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    float lsum = 0.f;
+    if (gid < total) {
+        const int wq = (int)(gid % x.W);
+        const long long t = gid / x.W;
+        const int h = (int)(t % x.H);
+        const int n = (int)(t / x.H);
+        float a0 = 0.f, a1 = 0.f;
+        const float* aff = (h < x.hsplit) ? x.aff0 : x.aff1;
+        for (int c = 0; c < x.C; ++c) {
+            float sc = 1.f, sh = 0.f;
+            if (aff) { sc = aff[2 * c]; sh = aff[2 * c + 1]; }
+            float v = fmaf(x.p[(long long)n * x.sN + (long long)c * x.sC + (long long)h * x.sH + wq], sc, sh);
+            v = v > 0.f ? v : v * x.slope;
+            a0 = fmaf(w[c], v, a0);
+            a1 = fmaf(w[x.C + c], v, a1);
+        }
+        const float lg[2] = {a0, a1};
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const float m = 1.f / (1.f + expf(-lg[o]));
+            float dm = 0.f;
+            const int reps = (h == x.H - 1) ? bins - x.H + 1 : 1;      // replicate-pad rows share the last logit
+            for (int e = 0; e < reps; ++e) {
+                const long long off = (((long long)n * 2 + o) * bins + h + e) * x.W + wq;
+                const float xv = X[off];
+                const float diff = m * xv - Y[off];
+                lsum += fabsf(diff);
+                dm += (diff > 0.f ? xv : (diff < 0.f ? -xv : 0.f));
+                if (mask_out) mask_out[off] = m;
+            }
+            dlogit[(((long long)n * 2 + o) * x.H + h) * x.W + wq] = dm * gscale * m * (1.f - m);
+        }
+    }
+    __shared__ float red[4];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) lsum += __shfl_xor(lsum, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) loss_part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+int head_loss_blocks(const Tensor& x) { return (int)(((long long)x.N * x.H * x.W + 255) / 256); }
+
+void launch_head_loss(const Tensor& x, const float* w, const float* X, const float* Y, int bins, float gscale,
+                      float* dlogit, float* mask_out, float* loss_part, float* loss_out, float loss_scale, hipStream_t st) {
+    const int nb = head_loss_blocks(x);
+    hipLaunchKernelGGL(head_loss_kernel, dim3(nb), dim3(256), 0, st, x, w, X, Y, bins, gscale, dlogit, mask_out, loss_part);
+    VR_HIP(hipGetLastError());
+    launch_reduce_rows(loss_part, 1, nb, loss_out, 1, 0, loss_scale, st);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Weights for the data-gradient: WT[co][KK-1-tap][ci] (CinPad) <- W[ci][tap][co] (CoutPad)
+// ---------------------------------------------------------------------------------------------------
+__global__ void flip_transpose_kernel(const FlipDesc* descs) {
+    const FlipDesc d = descs[blockIdx.y];
+    const int total = d.Cin * d.KK * d.Cout;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int co = i % d.Cout;
+        const int t = i / d.Cout;
+        const int tap = t % d.KK, ci = t / d.KK;
+        d.wt[((long long)co * d.KK + (d.KK - 1 - tap)) * d.CinPad + ci] = d.w[((long long)ci * d.KK + tap) * d.CoutPad + co];
+    }
+}
+void launch_flip_transpose(const FlipDesc* d_descs, int n, hipStream_t st) {
+    hipLaunchKernelGGL(flip_transpose_kernel, dim3(64, n), dim3(256), 0, st, d_descs);
+    VR_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------
+// torch.optim.Adam defaults (train.py:215-218) over the flat parameter arena, one launch.
+// ---------------------------------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long long n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i] * gscale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+}
+void launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
+                 long long step, float gscale, hipStream_t st) {
+    const float bc1 = 1.f - powf(b1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(b2, (float)step));
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, bc1,
+                       bc2s, gscale);
+    VR_HIP(hipGetLastError());
+}
+
+// sum over (n, w) per channel of d [N][C][W]  ->  out[c]      (bias gradients)
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ d, int N, int C, int W,
+                                                          float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int e = threadIdx.x; e < N * W; e += 256) s += d[((long long)(e / W) * C + c) * W + e % W];
+    __shared__ float red[4];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float v = red[0] + red[1] + red[2] + red[3];
+        out[c] = accumulate ? out[c] + v : v;
+    }
+}
+void launch_channel_sum(const float* d, int N, int C, int W, float* out, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, st, d, N, C, W, out, accumulate);
+    VR_HIP(hipGetLastError());
+}
+
+}  // namespace vr

@@ -18,13 +18,9 @@
 // fp32 MFMA runs at the fp32 vector rate (157 TFLOP/s peak) but reaches it with one LDS read
 // per operand per 64-cycle instruction, which is what makes a >100 TFLOP/s conv reachable; the
 // VALU stays free for the staging transforms.
-#include "vr_common.h"
+#include "conv_stage.h"
 
 namespace vr {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-__device__ __forceinline__ float act_apply(float v, float slope) { return v > 0.f ? v : v * slope; }
 
 template <int KS, int S, int DH, int DW, int MT, int TH, int TW, int CK, int WAVES_M>
 struct ConvCfg {
@@ -134,89 +130,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                 }
             }
         }
-        // ---------------- stage input: one channel per wave pass, lanes over the haloed tile ----
-#pragma unroll 1
-        for (int cl = wave; cl < CK; cl += 4) {
-            const int ci = c0 + cl;               // wave-uniform
-            float* dst = Xs + cl * TH_in * TWp;
-            constexpr int NE = TH_in * TW_in;
-            constexpr int NP = (NE + 63) / 64;
-            if (ci >= a.Cin) {
-                for (int e = lane; e < NE; e += 64) dst[(e / TW_in) * TWp + (e % TW_in)] = 0.f;
-                continue;
-            }
-            const int si = (ci >= a.c1) + (ci >= a.c2);
-            const ConvSrc& s = a.src[si];
-            const int clc = ci - (si == 0 ? 0 : (si == 1 ? a.c1 : a.c2));
-            const float* base = s.p + (long long)n * s.sN + (long long)clc * s.sC;
-            float sc0 = 1.f, sh0 = 0.f, sc1 = 1.f, sh1 = 0.f;
-            if (s.aff0) { sc0 = s.aff0[2 * clc]; sh0 = s.aff0[2 * clc + 1]; }
-            if (s.aff1) { sc1 = s.aff1[2 * clc]; sh1 = s.aff1[2 * clc + 1]; }
-            const float post = s.post ? s.post[n * s.C + clc] : 1.f;
-            const float slope = s.slope;
-            if (!s.up) {
-                constexpr int PB = NP < 6 ? NP : 6;
-#pragma unroll 1
-                for (int p0 = 0; p0 < NP; p0 += PB) {
-                    float raw[PB];
-#pragma unroll
-                    for (int j = 0; j < PB; ++j) {
-                        int e = lane + (p0 + j) * 64;
-                        e = e < NE ? e : NE - 1;
-                        int hi = hbase + e / TW_in, wi = wbase + e % TW_in;
-                        hi = hi < 0 ? 0 : (hi >= a.Hin ? a.Hin - 1 : hi);
-                        wi = wi < 0 ? 0 : (wi >= a.Win ? a.Win - 1 : wi);
-                        raw[j] = base[(long long)hi * s.sH + wi];
-                    }
-#pragma unroll
-                    for (int j = 0; j < PB; ++j) {
-                        const int e = lane + (p0 + j) * 64;
-                        const int hh = e / TW_in, ww = e % TW_in;
-                        const int hi = hbase + hh, wi = wbase + ww;
-                        const bool lo = hi < s.hsplit;
-                        float v = act_apply(fmaf(raw[j], lo ? sc0 : sc1, lo ? sh0 : sh1), slope) * post;
-                        if (!(hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win)) v = 0.f;
-                        if (e < NE) dst[hh * TWp + ww] = v;
-                    }
-                }
-            } else {
-                // bilinear x2, align_corners=True (torch upsample_bilinear2d): src = dst*(in-1)/(out-1)
-                constexpr int PB = NP < 3 ? NP : 3;
-#pragma unroll 1
-                for (int p0 = 0; p0 < NP; p0 += PB) {
-                    float r00[PB], r01[PB], r10[PB], r11[PB];
-#pragma unroll
-                    for (int j = 0; j < PB; ++j) {
-                        int e = lane + (p0 + j) * 64;
-                        e = e < NE ? e : NE - 1;
-                        int hi = hbase + e / TW_in, wi = wbase + e % TW_in;
-                        hi = hi < 0 ? 0 : (hi >= a.Hin ? a.Hin - 1 : hi);
-                        wi = wi < 0 ? 0 : (wi >= a.Win ? a.Win - 1 : wi);
-                        const int h1 = (int)(s.rh * (float)hi), w1 = (int)(s.rw * (float)wi);
-                        const int h1p = (h1 < s.H - 1) ? 1 : 0, w1p = (w1 < s.W - 1) ? 1 : 0;
-                        const float* q0 = base + (long long)h1 * s.sH + w1;
-                        const float* q1 = q0 + (long long)h1p * s.sH;
-                        r00[j] = q0[0]; r01[j] = q0[w1p]; r10[j] = q1[0]; r11[j] = q1[w1p];
-                    }
-#pragma unroll
-                    for (int j = 0; j < PB; ++j) {
-                        const int e = lane + (p0 + j) * 64;
-                        const int hh = e / TW_in, ww = e % TW_in;
-                        const int hi = hbase + hh, wi = wbase + ww;
-                        const float h1r = s.rh * (float)hi, w1r = s.rw * (float)wi;
-                        const float h1l = h1r - (float)(int)h1r, w1l = w1r - (float)(int)w1r;
-                        const float h0l = 1.f - h1l, w0l = 1.f - w1l;
-                        const float v00 = act_apply(fmaf(r00[j], sc0, sh0), slope);
-                        const float v01 = act_apply(fmaf(r01[j], sc0, sh0), slope);
-                        const float v10 = act_apply(fmaf(r10[j], sc0, sh0), slope);
-                        const float v11 = act_apply(fmaf(r11[j], sc0, sh0), slope);
-                        float v = (h0l * (w0l * v00 + w1l * v01) + h1l * (w0l * v10 + w1l * v11)) * post;
-                        if (!(hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win)) v = 0.f;
-                        if (e < NE) dst[hh * TWp + ww] = v;
-                    }
-                }
-            }
-        }
+        stage_input_chunk<TH_in, TW_in, TWp, TH_in * TWp, CK, 4>(a, Xs, c0, n, hbase, wbase, wave, lane);
         __syncthreads();
         // ---------------- MFMA over this chunk ---------------------------------------------------
         const int cleft = a.Cin - c0;
@@ -240,7 +154,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         }
     }
 
-    // ---------------- epilogue: raw store (+bias) --------------------------------------------------
+    // ---------------- epilogue: raw store (+bias), up to three destination segments -------------------
     // C/D layout of 32x32 MFMA: col (pixel) = lane & 31, row (cout) = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int mi = 0; mi < WM; ++mi) {
@@ -248,14 +162,19 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + (wm * WM + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
             const float b = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+            const int seg = (co >= a.d1) + (co >= a.d2);
+            const ConvDst& d = a.dst[seg];
+            const int cod = co - (seg == 0 ? 0 : (seg == 1 ? a.d1 : a.d2));
 #pragma unroll
             for (int ni = 0; ni < WN; ++ni) {
                 const int pix = (wn * WN + ni) * 32 + l31;
                 const int ho = h0 + pix / TW, wo = w0 + pix % TW;
                 const float v = acc[mi][ni][r] + b;
                 acc[mi][ni][r] = v;
-                if (co < a.Cout && ho < a.Hout && wo < a.Wout)
-                    a.out[(long long)n * a.oN + (long long)co * a.oC + (long long)ho * a.oH + wo] = v;
+                if (co < a.Cout && ho < a.Hout && wo < a.Wout && d.p) {
+                    float* q = d.p + (long long)n * d.sN + (long long)cod * d.sC + (long long)ho * d.sH + wo;
+                    *q = d.accumulate ? *q + v : v;
+                }
             }
         }
     }

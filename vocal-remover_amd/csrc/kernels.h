@@ -36,7 +36,7 @@ void launch_bn_finalize(const BNFinalizeArgs& a, hipStream_t st);
 
 // in-place rows affine + relu on [N][R][W]: v = relu(v*aff[r][0] + aff[r][1])  (BatchNorm1d + ReLU
 // of lib/layers.py:120-121 applied to the Linear output laid out [N, nbins, nframes])
-void launch_rows_affine_relu(float* x, const float* aff, int N, int R, int W, hipStream_t st);
+void launch_rows_affine_relu(const float* x, float* out, const float* aff, int N, int R, int W, hipStream_t st);
 
 // out[i] = a[i] + b[i]
 void launch_add(const float* a, const float* b, float* out, int n, hipStream_t st);
@@ -49,6 +49,54 @@ void launch_materialize(const Tensor& x, float* out, hipStream_t st);
 // out: [N][2H][T] (forward hidden in channels [0,H), reverse in [H,2H)).
 void launch_bilstm(const float* gx, const float* whh_f, const float* whh_r, float* out,
                    int N, int T, int H, hipStream_t st);
+
+// training variants: `save` [N][2][T][5H] keeps (i, f, g, o, c) per step for the backward pass
+void launch_bilstm_train(const float* gx, const float* whh_f, const float* whh_r, float* out, float* save,
+                         int N, int T, int H, hipStream_t st);
+// dh [N][2H][T] (gradient at the LSTM output) -> dgx [N][8H][T] (gradient at the input projections)
+void launch_bilstm_bwd(const float* dh, const float* save, const float* whh_f, const float* whh_r, float* dgx,
+                       int N, int T, int H, hipStream_t st);
+// dW_hh[dir][g][k] = sum_{n,t} dgx[n][dir*4H+g][t] * h_prev[n][dir*H+k][t]
+void launch_lstm_whh_grad(const float* dgx, const float* hout, float* dwhh_f, float* dwhh_r, int N, int T, int H,
+                          int accumulate, hipStream_t st);
+
+// ---- backward.hip -------------------------------------------------------------------------------
+struct BnBwdArgs {
+    float* g;                       // in: G (grad wrt post-activation value); out: dz (in place)
+    const float* z;                 // raw conv output, same strides as g
+    int N, C, H, W;
+    long long sN, sC, sH;
+    const float* aff;               // [C][2] scale, shift used in the forward (null = identity)
+    int aff_bcast;                  // 1: C == 1 and the table is a broadcast copy (use row 0)
+    float slope;
+    const float* post;              // [N][C] dropout keep-mask or null
+    const float *gamma, *save_mean, *save_invstd;
+    float *dgamma, *dbeta;          // gradient arena slots
+    int acc_grads;
+    float* coef;                    // [C][3] scratch (kA, kB, kC); null = no BatchNorm (dz = dy)
+    float* part;                    // [chunks][C][2] scratch
+};
+int bn_bwd_chunks(const BnBwdArgs& a);
+void launch_bn_bwd(const BnBwdArgs& a, hipStream_t st);
+
+void launch_upsample_bwd(const float* dhi, int N, int C, int H, int W, float* glo, long long gN, long long gC,
+                         long long gH, hipStream_t st);
+void launch_sum_h(const float* d, int N, int C, int H, int W, float* out, hipStream_t st);
+void launch_avgpool_bwd(const float* gp, float* g, int N, int C, int H, int W, long long sN, long long sC, long long sH,
+                        hipStream_t st);
+void launch_thin_dgrad(const Tensor& x, int CO, const float* w, const float* dz, float* g, int accumulate, hipStream_t st);
+int thin_wgrad_blocks(const Tensor& x);
+void launch_thin_wgrad(const Tensor& x, int CO, const float* dz, float* part, float* dw, int accumulate, hipStream_t st);
+void launch_reduce_rows(const float* part, long long stride, int P, float* out, long long n, int accumulate, float scale,
+                        hipStream_t st);
+int head_loss_blocks(const Tensor& x);
+void launch_head_loss(const Tensor& x, const float* w, const float* X, const float* Y, int bins, float gscale,
+                      float* dlogit, float* mask_out, float* loss_part, float* loss_out, float loss_scale, hipStream_t st);
+struct FlipDesc { const float* w; float* wt; int Cin, Cout, KK, CinPad, CoutPad; };
+void launch_flip_transpose(const FlipDesc* d_descs, int n, hipStream_t st);
+void launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
+                 long long step, float gscale, hipStream_t st);
+void launch_channel_sum(const float* d, int N, int C, int W, float* out, int accumulate, hipStream_t st);
 
 // ---- stft.hip -----------------------------------------------------------------------------------
 struct FFTPlan { int n_fft; int log2n; float2* twiddle; float* window; };

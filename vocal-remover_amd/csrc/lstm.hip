@@ -13,7 +13,8 @@ namespace vr {
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
 __global__ void bilstm_kernel(const float* __restrict__ gx, const float* __restrict__ whh_f,
-                              const float* __restrict__ whh_r, float* __restrict__ out, int T, int H) {
+                              const float* __restrict__ whh_r, float* __restrict__ out, float* __restrict__ save,
+                              int T, int H) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int G = 4 * H;
     float* WT = lds;               // [H][G]
@@ -51,14 +52,18 @@ __global__ void bilstm_kernel(const float* __restrict__ gx, const float* __restr
             const float h = og * tanhf(c);
             hbuf[g] = h;
             outp[t] = h;
+            if (save) {
+                float* sv = save + (((long long)n * 2 + dir) * T + t) * 5 * H + g;
+                sv[0] = ig; sv[H] = fg; sv[2 * H] = gg; sv[3 * H] = og; sv[4 * H] = c;
+            }
         }
         __syncthreads();
         pre = nxt;
     }
 }
 
-void launch_bilstm(const float* gx, const float* whh_f, const float* whh_r, float* out,
-                   int N, int T, int H, hipStream_t st) {
+void launch_bilstm_train(const float* gx, const float* whh_f, const float* whh_r, float* out, float* save,
+                         int N, int T, int H, hipStream_t st) {
     const int G = 4 * H;
     VR_CHECK(G <= 1024, -2, "LSTM hidden size per direction must be <= 256");
     const int threads = ((G + 63) / 64) * 64;
@@ -70,7 +75,109 @@ void launch_bilstm(const float* gx, const float* whh_f, const float* whh_r, floa
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(bilstm_kernel, dim3(N, 2), dim3(threads), lds, st, gx, whh_f, whh_r, out, T, H);
+    hipLaunchKernelGGL(bilstm_kernel, dim3(N, 2), dim3(threads), lds, st, gx, whh_f, whh_r, out, save, T, H);
+    VR_HIP(hipGetLastError());
+}
+
+void launch_bilstm(const float* gx, const float* whh_f, const float* whh_r, float* out,
+                   int N, int T, int H, hipStream_t st) {
+    launch_bilstm_train(gx, whh_f, whh_r, out, nullptr, N, T, H, st);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Backward through time.  One workgroup per (sample, direction), walking the forward order in
+// reverse; W_hh ([4H][H], gate-major) stays in LDS, dh_{t-1} = W_hh^T da_t is a 4-way split
+// reduction over the gates.
+// ---------------------------------------------------------------------------------------------------
+__global__ void bilstm_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ save,
+                                  const float* __restrict__ whh_f, const float* __restrict__ whh_r,
+                                  float* __restrict__ dgx, int T, int H) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int G = 4 * H;
+    float* W = lds;              // [G][H]
+    float* da = W + G * H;       // [G]
+    float* dhn = da + G;         // [H]
+    float* part = dhn + H;       // [4][H]
+    const int n = blockIdx.x, dir = blockIdx.y;
+    const int j = threadIdx.x;
+    const float* whh = dir ? whh_r : whh_f;
+    for (int i = threadIdx.x; i < G * H; i += blockDim.x) W[i] = whh[i];
+    if (j < H) dhn[j] = 0.f;
+    float dc_next = 0.f;
+    const float* svb = save + ((long long)n * 2 + dir) * T * 5 * H;
+    const float* dhp = dh + ((long long)n * 2 * H + (long long)dir * H + j) * T;
+    float* dgp = dgx + ((long long)n * 2 * G + (long long)dir * G) * T;
+    __syncthreads();
+    for (int step = T - 1; step >= 0; --step) {
+        const int t = dir ? T - 1 - step : step;
+        if (j < H) {
+            const float* sv = svb + (long long)t * 5 * H + j;
+            const float ig = sv[0], fg = sv[H], gg = sv[2 * H], og = sv[3 * H], c = sv[4 * H];
+            float c_prev = 0.f;
+            if (step > 0) c_prev = svb[(long long)(dir ? t + 1 : t - 1) * 5 * H + 4 * H + j];
+            const float dht = dhp[t] + dhn[j];
+            const float tc = tanhf(c);
+            const float d_o = dht * tc;
+            const float dc = dht * og * (1.f - tc * tc) + dc_next;
+            const float d_i = dc * gg, d_g = dc * ig, d_f = dc * c_prev;
+            dc_next = dc * fg;
+            const float a_i = d_i * ig * (1.f - ig), a_f = d_f * fg * (1.f - fg);
+            const float a_g = d_g * (1.f - gg * gg), a_o = d_o * og * (1.f - og);
+            da[j] = a_i; da[H + j] = a_f; da[2 * H + j] = a_g; da[3 * H + j] = a_o;
+            dgp[(long long)j * T + t] = a_i;
+            dgp[(long long)(H + j) * T + t] = a_f;
+            dgp[(long long)(2 * H + j) * T + t] = a_g;
+            dgp[(long long)(3 * H + j) * T + t] = a_o;
+        }
+        __syncthreads();
+        if (j < G) {
+            const int q = j / H, k = j % H;
+            float s = 0.f;
+            for (int g = q * H; g < (q + 1) * H; ++g) s = fmaf(W[g * H + k], da[g], s);
+            part[q * H + k] = s;
+        }
+        __syncthreads();
+        if (j < H) dhn[j] = part[j] + part[H + j] + part[2 * H + j] + part[3 * H + j];
+        __syncthreads();
+    }
+}
+
+void launch_bilstm_bwd(const float* dh, const float* save, const float* whh_f, const float* whh_r, float* dgx,
+                       int N, int T, int H, hipStream_t st) {
+    const int G = 4 * H;
+    const int threads = ((G + 63) / 64) * 64;
+    const size_t lds = (size_t)(G * H + G + H + 4 * H) * sizeof(float);
+    VR_CHECK(G <= 1024 && lds <= 160 * 1024, -2, "LSTM hidden size too large for the LDS-resident backward");
+    static bool attr_set = false;
+    if (!attr_set) {
+        VR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bilstm_bwd_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(bilstm_bwd_kernel, dim3(N, 2), dim3(threads), lds, st, dh, save, whh_f, whh_r, dgx, T, H);
+    VR_HIP(hipGetLastError());
+}
+
+__global__ void lstm_whh_grad_kernel(const float* __restrict__ dgx, const float* __restrict__ hout, float* dwf, float* dwr,
+                                     int N, int T, int H, int accumulate) {
+    const int g = blockIdx.x, dir = blockIdx.y;
+    const int G = 4 * H;
+    float* dw = dir ? dwr : dwf;
+    for (int k = threadIdx.x; k < H; k += blockDim.x) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const float* dg = dgx + ((long long)n * 2 * G + (long long)dir * G + g) * T;
+            const float* hp = hout + ((long long)n * 2 * H + (long long)dir * H + k) * T;
+            if (dir == 0) { for (int t = 1; t < T; ++t) s = fmaf(dg[t], hp[t - 1], s); }
+            else          { for (int t = 0; t < T - 1; ++t) s = fmaf(dg[t], hp[t + 1], s); }
+        }
+        dw[g * H + k] = accumulate ? dw[g * H + k] + s : s;
+    }
+}
+
+void launch_lstm_whh_grad(const float* dgx, const float* hout, float* dwhh_f, float* dwhh_r, int N, int T, int H,
+                          int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(lstm_whh_grad_kernel, dim3(4 * H, 2), dim3(64), 0, st, dgx, hout, dwhh_f, dwhh_r, N, T, H, accumulate);
     VR_HIP(hipGetLastError());
 }
 

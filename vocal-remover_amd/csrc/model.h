@@ -43,6 +43,7 @@ struct Param {
     Param* alias_of = nullptr;      // PK_LSTM_IH reverse half lives inside the forward half's buffer
     float* dev = nullptr;
     int64_t nbt = 0;                // PK_NBT value (host)
+    float* grad_override = nullptr; // test hook: gradient slot outside the arena
 };
 
 struct BN {
@@ -162,8 +163,59 @@ private:
 
     // executor
     struct SrcSpec { Tensor t; bool up = false; int bcastH = 0; };
+    // ---- training tape: forward order == topological order, backward walks it in reverse ----
+    enum TapeKind { TK_CONV, TK_AVGPOOL, TK_SQUEEZE, TK_LSTM, TK_DENSE_ACT };
+    struct TapeRec {
+        TapeKind kind;
+        Conv* L = nullptr;
+        std::vector<SrcSpec> srcs;
+        Tensor out;                  // raw output (+ g)
+        int N = 0;
+        bool batch_as_h = false;
+        const float* bias = nullptr;
+        Param* bias_param = nullptr;           // dense bias (gradient = channel sums of dz)
+        LSTMMod* M = nullptr;                  // TK_LSTM / TK_SQUEEZE / TK_DENSE_ACT
+        Tensor aux;                            // kind-specific second tensor
+        float* save = nullptr;                 // LSTM gate/cell record
+        float* buf0 = nullptr;                 // kind-specific buffers
+        float* buf1 = nullptr;
+    };
+    std::vector<TapeRec> tape;
+    Arena gs;                                            // gradients of activations (zeroed per step)
+    float* g_arena = nullptr;                            // gradients of parameters (mirrors p_arena)
+    float* m_arena = nullptr; float* v_arena = nullptr;  // Adam moments
+    float* wt_arena = nullptr; size_t wt_floats = 0;     // flipped/transposed conv weights for dgrad
+    FlipDesc* d_flip = nullptr; int n_flip = 0;
+    std::map<const Param*, float*> wt_of;
+    long long adam_step = 0;
+    float* grad_of(const Param* p) { return p->grad_override ? p->grad_override : g_arena + (p->dev - p_arena); }
+public:
+    void debug_conv_bwd(const float* x, int N, int Cin, int H, int W, const float* w_oihw, int Cout, int KS, int stride,
+                        int dh, int dw, int up, const float* aff, float slope, const float* dz, float* dx_out,
+                        float* dw_out);
+private:
+    void ensure_train_state();
+    void backward();
+    void bwd_conv(TapeRec& r);
+    void bwd_bn_of(const Tensor& out, Conv& L);
+    std::vector<float> dropout_host;                     // injected keep-masks [5][N][8*nout] or empty
+    int dropout_mode = 0;                                // 0 off, 1 native RNG, 2 injected
+    unsigned long long dropout_seed = 0;
+    float* dropout_buf = nullptr; size_t dropout_cap = 0;
+public:
+    // train.py:77-96: forward (train mode) + L1 loss + backward; gradients accumulate in the arena.
+    void train_fwd_bwd_api(const float* X, const float* Y, bool on_dev, int B, int T, int accumulation_steps,
+                           float* loss_out, float* mask_out, bool mask_on_dev);
+    void adam_step_api(float lr, float b1, float b2, float eps, float grad_scale);
+    void zero_grad_api();
+    void get_grad(const std::string& key, float* host, int64_t cap_bytes);
+    void set_dropout(int mode, unsigned long long seed, const float* masks, int B);
+    void grad_arena(float** ptr, int64_t* numel);
+private:
+    void build_fwd_args(Conv& L, const std::vector<SrcSpec>& srcs, int N, bool batch_as_h, ConvArgs& a);
     Tensor run_conv(Conv& L, const std::vector<SrcSpec>& srcs, int N, const Tensor* out_view, const float* bias,
                     bool batch_as_h);
+    template <class F> void for_each_conv(F&& f);
     Tensor run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, const Tensor* out_view);
     Tensor run_lstm(LSTMMod& M, const Tensor& h);
     Tensor run_net(const Tensor& x);                     // -> stg3 dec1 output (raw + affine)

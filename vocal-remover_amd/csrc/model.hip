@@ -216,7 +216,8 @@ Model::~Model() {
     hipSetDevice(device);
     if (stream) hipStreamSynchronize(stream);
     hipFree(p_arena); hipFree(b_arena); hipFree(d_fold);
-    hipFree(ws.base); hipFree(io.base);
+    hipFree(ws.base); hipFree(io.base); hipFree(gs.base);
+    hipFree(g_arena); hipFree(m_arena); hipFree(v_arena); hipFree(wt_arena); hipFree(d_flip); hipFree(dropout_buf);
     hipFree(plan.twiddle); hipFree(plan.window);
     if (stream) hipStreamDestroy(stream);
 }
@@ -382,22 +383,22 @@ int64_t Model::get_tap(const std::string& name, float* host, int64_t cap_floats,
 // =====================================================================================================
 // executor
 // =====================================================================================================
-static ConvSrc make_src(const Tensor& t, bool up, int bcastH) {
+ConvSrc make_src(const Tensor& t, bool up, int bcastH) {
     ConvSrc s{};
     s.p = t.p; s.aff0 = t.aff0; s.aff1 = t.aff1 ? t.aff1 : t.aff0;
     s.sN = t.sN; s.sC = t.sC; s.sH = t.sH;
     s.C = t.C; s.H = t.H; s.W = t.W;
-    s.hsplit = t.hsplit; s.slope = t.slope; s.up = up ? 1 : 0; s.post = t.post;
+    s.hsplit = t.hsplit; s.slope = t.slope; s.up = up ? 1 : 0; s.post = t.post; s.zins = 0;
     s.rh = (t.H > 0) ? (float)(t.H - 1) / (float)(2 * t.H - 1) : 0.f;
     s.rw = (t.W > 0) ? (float)(t.W - 1) / (float)(2 * t.W - 1) : 0.f;
     if (bcastH) { s.sH = 0; s.H = bcastH; }
     return s;
 }
 
-Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs, int N, const Tensor* out_view, const float* bias,
-                       bool batch_as_h) {
+// Forward launch description of a conv layer (shared by the forward pass and the weight gradient).
+void Model::build_fwd_args(Conv& L, const std::vector<SrcSpec>& srcs, int N, bool batch_as_h, ConvArgs& a) {
     VR_CHECK(!srcs.empty() && srcs.size() <= 3, -2, "conv " + L.name + ": 1..3 sources");
-    ConvArgs a{};
+    a = ConvArgs{};
     a.nsrc = (int)srcs.size();
     int Hin = -1, Win = -1, ctot = 0;
     for (int i = 0; i < a.nsrc; ++i) {
@@ -416,8 +417,8 @@ Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs, int N, const T
     a.c2 = a.nsrc >= 3 ? srcs[0].t.C + srcs[1].t.C : L.Cin;
     a.Cin = L.Cin;
     a.w = L.w->dev;
-    a.bias = bias;
     a.Cout = L.Cout; a.CoutPad = L.CoutPad;
+    a.d1 = a.d2 = 1 << 30;
     int Nk = N;
     if (batch_as_h) {
         VR_CHECK(L.KS == 1 && Hin == 1, -2, "batch-as-rows view needs a 1x1 conv on H=1 input");
@@ -431,22 +432,33 @@ Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs, int N, const T
     a.Hout = (Hin + 2 * L.pad_h - L.dh * (L.KS - 1) - 1) / L.stride + 1;
     a.Wout = (Win + 2 * L.pad_w - L.dw * (L.KS - 1) - 1) / L.stride + 1;
     a.pad_h = L.pad_h; a.pad_w = L.pad_w;
+}
+
+Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs, int N, const Tensor* out_view, const float* bias,
+                       bool batch_as_h) {
+    ConvArgs a;
+    build_fwd_args(L, srcs, N, batch_as_h, a);
+    a.bias = bias;
     Tensor o;
     if (batch_as_h) {
         o.N = N; o.C = L.Cout; o.H = 1; o.W = a.Wout;
-        if (out_view) { o.p = out_view->p; o.sN = out_view->sN; o.sC = out_view->sC; o.sH = out_view->sH; }
-        else { o.p = ws.allocf((size_t)N * L.Cout * a.Wout); o.sN = (long long)L.Cout * a.Wout; o.sC = a.Wout; o.sH = a.Wout; }
-        a.out = o.p; a.oN = 0; a.oC = o.sC; a.oH = o.sN;
+        if (out_view) { o.p = out_view->p; o.g = out_view->g; o.sN = out_view->sN; o.sC = out_view->sC; o.sH = out_view->sH; }
+        else {
+            o.p = ws.allocf((size_t)N * L.Cout * a.Wout); o.sN = (long long)L.Cout * a.Wout; o.sC = a.Wout; o.sH = a.Wout;
+            if (training) o.g = gs.allocf((size_t)N * L.Cout * a.Wout);
+        }
+        a.dst[0] = ConvDst{o.p, 0, o.sC, o.sN, 0};
     } else {
         o.N = N; o.C = L.Cout; o.H = a.Hout; o.W = a.Wout;
         if (out_view) {
             VR_CHECK(out_view->H == a.Hout && out_view->W == a.Wout && out_view->C == L.Cout, -2, "conv " + L.name + ": output view shape mismatch");
-            o.p = out_view->p; o.sN = out_view->sN; o.sC = out_view->sC; o.sH = out_view->sH;
+            o.p = out_view->p; o.g = out_view->g; o.sN = out_view->sN; o.sC = out_view->sC; o.sH = out_view->sH;
         } else {
             o.p = ws.allocf((size_t)N * L.Cout * a.Hout * a.Wout);
             o.sH = a.Wout; o.sC = (long long)a.Hout * a.Wout; o.sN = o.sC * L.Cout;
+            if (training) o.g = gs.allocf((size_t)N * L.Cout * a.Hout * a.Wout);
         }
-        a.out = o.p; a.oN = o.sN; a.oC = o.sC; a.oH = o.sH;
+        a.dst[0] = ConvDst{o.p, o.sN, o.sC, o.sH, 0};
     }
     const ConvShape shp{L.KS, L.stride, L.dh, L.dw};
     const bool stats = training && L.bn;
@@ -472,6 +484,11 @@ Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs, int N, const T
         }
     }
     if (L.bn) { o.aff0 = L.bn->affine; o.slope = L.slope; } else { o.aff0 = nullptr; o.slope = 1.f; }
+    if (training) {
+        TapeRec r;
+        r.kind = TK_CONV; r.L = &L; r.srcs = srcs; r.out = o; r.N = N; r.batch_as_h = batch_as_h; r.bias = bias;
+        tape.push_back(std::move(r));
+    }
     return o;
 }
 
@@ -501,6 +518,14 @@ Tensor Model::run_lstm(LSTMMod& M, const Tensor& h) {
     zt.p = z; zt.N = N; zt.C = nb; zt.H = 1; zt.W = nf;
     zt.sN = (long long)nb * nf; zt.sC = nf; zt.sH = nf;
     zt.aff0 = M.squeeze.bn->affine; zt.slope = 0.f;
+    if (training) {
+        zt.g = gs.allocf((size_t)N * nb * nf);
+        TapeRec r;
+        r.kind = TK_SQUEEZE; r.M = &M; r.srcs = {SrcSpec{h}}; r.N = N;
+        r.out = zt;                      // as a 1-channel image [N,1,nb,nf] for its own BatchNorm backward
+        r.out.C = 1; r.out.H = nb; r.out.sC = (long long)nb * nf; r.out.sH = nf;
+        tape.push_back(std::move(r));
+    }
     const int G = 4 * M.hid;
     float* bias = ws.allocf((size_t)2 * G);
     if (!dry) {
@@ -509,14 +534,25 @@ Tensor Model::run_lstm(LSTMMod& M, const Tensor& h) {
     }
     Tensor gx = run_conv(M.proj, {SrcSpec{zt}}, N, nullptr, bias, true);       // [N][8H][nf]
     float* hc = ws.allocf((size_t)N * 2 * M.hid * nf);                          // [N][2H][nf]
-    if (!dry) launch_bilstm(gx.p, M.whh_f->dev, M.whh_r->dev, hc, N, nf, M.hid, stream);
+    float* save = training ? ws.allocf((size_t)N * 2 * nf * 5 * M.hid) : nullptr;
+    if (!dry) launch_bilstm_train(gx.p, M.whh_f->dev, M.whh_r->dev, hc, save, N, nf, M.hid, stream);
     Tensor ht;
     ht.p = hc; ht.N = N; ht.C = 2 * M.hid; ht.H = 1; ht.W = nf;
     ht.sN = (long long)2 * M.hid * nf; ht.sC = nf; ht.sH = nf; ht.slope = 1.f;
+    if (training) {
+        ht.g = gs.allocf((size_t)N * 2 * M.hid * nf);
+        TapeRec r;
+        r.kind = TK_LSTM; r.M = &M; r.N = N; r.out = ht; r.aux = gx; r.save = save;
+        tape.push_back(std::move(r));
+    }
     Tensor lin = run_conv(M.dense, {SrcSpec{ht}}, N, nullptr, M.dense_b->dev, true);   // [N][nb][nf] raw
-    if (!dry) launch_rows_affine_relu(lin.p, M.dense.bn->affine, N, nb, nf, stream);
+    if (training) tape.back().bias_param = M.dense_b;
+    // BatchNorm1d + ReLU (lib/layers.py:120-121).  Eval: in place.  Train: the raw values are what the
+    // BatchNorm backward needs, so the activated copy goes to its own buffer and shares lin's gradient.
+    float* act = training ? ws.allocf((size_t)N * nb * nf) : lin.p;
+    if (!dry) launch_rows_affine_relu(lin.p, act, M.dense.bn->affine, N, nb, nf, stream);
     Tensor o;                                                                   // [N,1,nb,nf], already activated
-    o.p = lin.p; o.N = N; o.C = 1; o.H = nb; o.W = nf;
+    o.p = act; o.g = lin.g; o.N = N; o.C = 1; o.H = nb; o.W = nf;
     o.sN = (long long)nb * nf; o.sC = (long long)nb * nf; o.sH = nf; o.slope = 1.f;
     return o;
 }
@@ -540,18 +576,26 @@ Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, co
     Tensor pt;
     pt.p = pooled; pt.N = N; pt.C = C8; pt.H = 1; pt.W = x5.W;
     pt.sN = (long long)C8 * x5.W; pt.sC = x5.W; pt.sH = x5.W; pt.slope = 1.f;
+    if (training) {
+        pt.g = gs.allocf((size_t)N * C8 * x5.W);
+        TapeRec r;
+        r.kind = TK_AVGPOOL; r.srcs = {SrcSpec{x5}}; r.out = pt; r.N = N;
+        tape.push_back(std::move(r));
+    }
     Tensor f1 = run_conv(B.aspp_pool, {SrcSpec{pt}}, N, nullptr, nullptr, true);
     // conv2..conv5 write channel slices of one [N, 4*C8, H, W] buffer (the concat is never built)
     Tensor cat4;
     cat4.N = N; cat4.C = 4 * C8; cat4.H = x5.H; cat4.W = x5.W;
     cat4.sH = x5.W; cat4.sC = (long long)x5.H * x5.W; cat4.sN = cat4.sC * cat4.C;
     cat4.p = ws.allocf((size_t)N * cat4.C * x5.H * x5.W);
+    if (training) cat4.g = gs.allocf((size_t)N * cat4.C * x5.H * x5.W);
     cat4.aff0 = B.aspp_aff; cat4.slope = 0.f;
     Conv* branch[4] = {&B.aspp_c2, &B.aspp_d[0], &B.aspp_d[1], &B.aspp_d[2]};
     for (int j = 0; j < 4; ++j) {
         Tensor v = cat4;
         v.C = C8;
         v.p = dry ? cat4.p : cat4.p + (long long)j * C8 * cat4.sC;
+        if (training && !dry) v.g = cat4.g + (long long)j * C8 * cat4.sC;
         run_conv(*branch[j], {SrcSpec{x5}}, N, &v, nullptr, false);
     }
     SrcSpec s1{f1};
@@ -560,6 +604,7 @@ Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, co
     if (training && dropout_dev) {
         int idx = (int)(&B - nets_);
         h.post = dropout_dev + (size_t)idx * N * 8 * nout;   // [5][N][8*nout] slots, row pitch 8c
+        tape.back().out.post = h.post;                        // the bottleneck's BatchNorm backward needs it
     }
     tap(p + ".aspp", h);
     // decoders (lib/layers.py:51-64): upsample x2 + skip concat + conv, all inside the conv's loader
@@ -589,13 +634,14 @@ Tensor Model::run_net(const Tensor& x) {
         t.N = B; t.C = C; t.H = max_bin; t.W = T;
         t.sH = T; t.sC = (long long)max_bin * T; t.sN = t.sC * C;
         t.p = ws.allocf((size_t)B * C * max_bin * T);
+        if (training) t.g = gs.allocf((size_t)B * C * max_bin * T);
         t.slope = 0.f;
         return t;
     };
     Tensor aux1 = make_aux(nout / 4), aux2 = make_aux(nout / 2);
     auto half = [&](const Tensor& a, int which) {
         Tensor v = a; v.H = bandw;
-        if (which && !dry) v.p = a.p + (long long)bandw * a.sH;
+        if (which && !dry) { v.p = a.p + (long long)bandw * a.sH; if (a.g) v.g = a.g + (long long)bandw * a.sH; }
         return v;
     };
     Tensor v;
@@ -875,7 +921,8 @@ void Model::debug_conv(const float* x, int N, int Cin, int H, int W, const float
     ConvArgs a{};
     a.nsrc = 1; a.src[0] = make_src(t, up != 0, 0); a.c1 = a.c2 = Cin; a.Cin = Cin;
     a.w = dw_; a.bias = dbias; a.Cout = Cout; a.CoutPad = CoutPad;
-    a.out = dout; a.oH = Wout; a.oC = (long long)Hout * Wout; a.oN = a.oC * Cout;
+    a.dst[0] = ConvDst{dout, (long long)Hout * Wout * Cout, (long long)Hout * Wout, (long long)Wout, 0};
+    a.d1 = a.d2 = 1 << 30;
     a.N = N; a.Hout = Hout; a.Wout = Wout; a.Hin = Hin; a.Win = Win; a.pad_h = pad_h; a.pad_w = pad_w;
     const ConvShape shp{KS, stride, dh, dw};
     size_t npt = 0;

@@ -196,17 +196,17 @@ void launch_bn_finalize(const BNFinalizeArgs& a, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-__global__ void rows_affine_relu_kernel(float* x, const float* aff, int R, int W, long long total) {
+__global__ void rows_affine_relu_kernel(const float* x, float* out, const float* aff, int R, int W, long long total) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
     const int r = (int)((gid / W) % R);
     const float v = fmaf(x[gid], aff[2 * r], aff[2 * r + 1]);
-    x[gid] = v > 0.f ? v : 0.f;
+    out[gid] = v > 0.f ? v : 0.f;
 }
 
-void launch_rows_affine_relu(float* x, const float* aff, int N, int R, int W, hipStream_t st) {
+void launch_rows_affine_relu(const float* x, float* out, const float* aff, int N, int R, int W, hipStream_t st) {
     const long long total = (long long)N * R * W;
-    hipLaunchKernelGGL(rows_affine_relu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, aff, R, W, total);
+    hipLaunchKernelGGL(rows_affine_relu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, out, aff, R, W, total);
     VR_HIP(hipGetLastError());
 }
 

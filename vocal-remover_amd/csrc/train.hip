@@ -1,0 +1,434 @@
+// Training executor: forward in train mode (model.hip) records a tape; this file walks it backwards
+// (train.py:81-96: loss = L1(mask*X, y); (loss/accumulation_steps).backward(); optimizer.step()).
+#include <cmath>
+#include <cstring>
+#include <random>
+
+#include "model.h"
+
+namespace vr {
+
+ConvSrc make_src(const Tensor& t, bool up, int bcastH);
+
+static inline int round_up32(int v) { return (v + 31) / 32 * 32; }
+
+template <class F>
+void Model::for_each_conv(F&& f) {
+    for (int i = 0; i < 5; ++i) {
+        BaseNetL& B = nets_[i];
+        f(B.enc1);
+        for (int j = 0; j < 4; ++j) { f(B.enc_a[j]); f(B.enc_b[j]); }
+        f(B.aspp_pool); f(B.aspp_c2);
+        for (int j = 0; j < 3; ++j) f(B.aspp_d[j]);
+        f(B.aspp_bott);
+        for (int j = 0; j < 4; ++j) f(B.dec[j]);
+        f(B.lstm.proj); f(B.lstm.dense);
+    }
+    f(tail1); f(tail2);
+}
+
+void Model::ensure_train_state() {
+    if (g_arena) return;
+    VR_HIP(hipMalloc(&g_arena, p_floats * sizeof(float)));
+    VR_HIP(hipMalloc(&m_arena, p_floats * sizeof(float)));
+    VR_HIP(hipMalloc(&v_arena, p_floats * sizeof(float)));
+    VR_HIP(hipMemset(g_arena, 0, p_floats * sizeof(float)));
+    VR_HIP(hipMemset(m_arena, 0, p_floats * sizeof(float)));
+    VR_HIP(hipMemset(v_arena, 0, p_floats * sizeof(float)));
+    // flipped + transposed copies of the conv weights for the data-gradient launches
+    size_t off = 0;
+    std::vector<std::pair<Conv*, size_t>> slots;
+    for_each_conv([&](Conv& L) {
+        const size_t n = (size_t)L.Cout * L.KS * L.KS * round_up32(L.Cin);
+        slots.push_back({&L, off});
+        off += (n + 63) & ~size_t(63);
+    });
+    wt_floats = off;
+    VR_HIP(hipMalloc(&wt_arena, wt_floats * sizeof(float)));
+    VR_HIP(hipMemset(wt_arena, 0, wt_floats * sizeof(float)));
+    std::vector<FlipDesc> descs;
+    for (auto& sl : slots) {
+        Conv& L = *sl.first;
+        wt_of[L.w] = wt_arena + sl.second;
+        descs.push_back(FlipDesc{L.w->dev, wt_arena + sl.second, L.Cin, L.Cout, L.KS * L.KS, round_up32(L.Cin), L.CoutPad});
+    }
+    n_flip = (int)descs.size();
+    VR_HIP(hipMalloc(&d_flip, descs.size() * sizeof(FlipDesc)));
+    VR_HIP(hipMemcpy(d_flip, descs.data(), descs.size() * sizeof(FlipDesc), hipMemcpyHostToDevice));
+}
+
+void Model::zero_grad_api() {
+    VR_HIP(hipSetDevice(device));
+    ensure_train_state();
+    VR_HIP(hipMemsetAsync(g_arena, 0, p_floats * sizeof(float), stream));
+    VR_HIP(hipStreamSynchronize(stream));
+}
+
+void Model::grad_arena(float** ptr, int64_t* numel) {
+    VR_HIP(hipSetDevice(device));
+    ensure_train_state();
+    *ptr = g_arena;
+    *numel = (int64_t)p_floats;
+}
+
+void Model::set_dropout(int mode, unsigned long long seed, const float* masks, int B) {
+    VR_CHECK(mode >= 0 && mode <= 2, -2, "dropout mode must be 0 (off), 1 (native RNG) or 2 (injected)");
+    dropout_mode = mode;
+    dropout_seed = seed;
+    dropout_host.clear();
+    if (mode == 2) {
+        VR_CHECK(masks && B > 0, -2, "injected dropout needs masks [5][B][8*nout]");
+        dropout_host.assign(masks, masks + (size_t)5 * B * 8 * nout);
+    }
+}
+
+// BatchNorm backward of a conv record: G -> dz in place, d(gamma), d(beta) into the gradient arena.
+void Model::bwd_bn_of(const Tensor& out, Conv& L) {
+    BN* b = L.bn;
+    BnBwdArgs a{};
+    a.g = out.g; a.z = out.p; a.N = out.N; a.C = out.C; a.H = out.H; a.W = out.W;
+    a.sN = out.sN; a.sC = out.sC; a.sH = out.sH;
+    a.aff = b->affine; a.aff_bcast = b->bcast ? 1 : 0; a.slope = L.slope; a.post = out.post;
+    a.gamma = b->w->dev; a.save_mean = b->save_mean; a.save_invstd = b->save_invstd;
+    a.dgamma = dry ? nullptr : grad_of(b->w); a.dbeta = dry ? nullptr : grad_of(b->b);
+    a.acc_grads = 1;
+    a.coef = ws.allocf((size_t)out.C * 3);
+    a.part = ws.allocf((size_t)bn_bwd_chunks(a) * out.C * 2);
+    if (!dry) launch_bn_bwd(a, stream);
+}
+
+void Model::bwd_conv(TapeRec& r) {
+    Conv& L = *r.L;
+    const Tensor& out = r.out;
+    const int N = r.N;
+    // 1. gradient at the raw conv output
+    if (L.bn) bwd_bn_of(out, L);
+    // (no BatchNorm: the only such convs -- LSTM input projection -- have identity activation: dz = G)
+    // 2. bias gradient (Linear bias): channel sums of dz laid out [N][C][W]
+    if (r.bias_param && !dry) launch_channel_sum(out.g, N, out.C, out.W, grad_of(r.bias_param), 1, stream);
+    // 3. weight gradient
+    ConvArgs f;
+    build_fwd_args(L, r.srcs, N, r.batch_as_h, f);
+    const ConvShape shp{L.KS, L.stride, L.dh, L.dw};
+    {
+        WgradArgs w{};
+        w.in = f;
+        w.dz = out.g;
+        if (r.batch_as_h) { w.zN = 0; w.zC = out.sC; w.zH = out.sN; }
+        else { w.zN = out.sN; w.zC = out.sC; w.zH = out.sH; }
+        w.Cout = L.Cout; w.CoutPad = L.CoutPad;
+        w.part = ws.allocf(wgrad_scratch_floats(w, shp));
+        if (!dry) {
+            record_begin(0, 2.0 * N * (double)(r.batch_as_h ? 1 : f.Hout) * f.Wout * (double)L.Cout * L.Cin * L.KS * L.KS);
+            launch_wgrad(w, shp, grad_of(L.w), 1, stream);
+            record_end();
+        }
+    }
+    // 4. data gradient, split back to the sources of the virtual concat
+    bool any = false;
+    for (auto& sp : r.srcs) any = any || sp.t.g != nullptr;
+    if (!any) return;
+    ConvArgs d{};
+    Tensor dzt = out;                       // dz as a plain source
+    dzt.p = out.g; dzt.aff0 = dzt.aff1 = nullptr; dzt.slope = 1.f; dzt.post = nullptr; dzt.hsplit = 1 << 30;
+    d.nsrc = 1;
+    d.src[0] = make_src(dzt, false, 0);
+    if (r.batch_as_h) { d.src[0].sH = d.src[0].sN; d.src[0].sN = 0; d.src[0].H = N; }
+    d.src[0].zins = (L.stride == 2) ? 1 : 0;
+    d.c1 = d.c2 = L.Cout; d.Cin = L.Cout;
+    d.w = dry ? nullptr : wt_of[L.w];
+    d.bias = nullptr;
+    d.Cout = L.Cin; d.CoutPad = round_up32(L.Cin);
+    d.N = f.N; d.Hin = f.Hin; d.Win = f.Win; d.Hout = f.Hin; d.Wout = f.Win;
+    d.pad_h = (L.KS == 1) ? 0 : L.dh; d.pad_w = (L.KS == 1) ? 0 : L.dw;
+    struct Post { int kind; float* tmp; const SrcSpec* sp; };
+    std::vector<Post> posts;
+    int cbase = 0;
+    for (size_t i = 0; i < r.srcs.size(); ++i) {
+        const SrcSpec& sp = r.srcs[i];
+        const Tensor& t = sp.t;
+        ConvDst ds{};
+        if (!t.g) {
+            ds.p = nullptr;
+        } else if (sp.up || sp.bcastH) {
+            const size_t n = (size_t)N * t.C * f.Hin * f.Win;
+            float* tmp = ws.allocf(n);
+            ds = ConvDst{tmp, (long long)t.C * f.Hin * f.Win, (long long)f.Hin * f.Win, (long long)f.Win, 0};
+            posts.push_back(Post{sp.up ? 1 : 2, tmp, &sp});
+        } else if (r.batch_as_h) {
+            ds = ConvDst{t.g, 0, t.sC, t.sN, 1};
+        } else {
+            ds = ConvDst{t.g, t.sN, t.sC, t.sH, 1};
+        }
+        d.dst[i] = ds;
+        cbase += t.C;
+        if (i == 0) d.d1 = cbase;
+        if (i == 1) d.d2 = cbase;
+    }
+    if (r.srcs.size() == 1) d.d1 = d.d2 = 1 << 30;
+    if (r.srcs.size() == 2) d.d2 = 1 << 30;
+    if (dry) return;
+    const ConvShape dshp{L.KS, 1, L.dh, L.dw};
+    record_begin(0, 2.0 * N * (double)(r.batch_as_h ? 1 : f.Hout) * f.Wout * (double)L.Cout * L.Cin * L.KS * L.KS);
+    launch_conv(d, dshp, stream);
+    record_end();
+    for (auto& p : posts) {
+        const Tensor& t = p.sp->t;
+        if (p.kind == 1) launch_upsample_bwd(p.tmp, N, t.C, t.H, t.W, t.g, t.sN, t.sC, t.sH, stream);
+        else launch_sum_h(p.tmp, N, t.C, f.Hin, f.Win, t.g, stream);
+    }
+}
+
+void Model::backward() {
+    for (size_t k = tape.size(); k-- > 0;) {
+        TapeRec& r = tape[k];
+        switch (r.kind) {
+        case TK_CONV:
+            bwd_conv(r);
+            break;
+        case TK_AVGPOOL: {
+            const Tensor& x5 = r.srcs[0].t;
+            if (!dry && x5.g) launch_avgpool_bwd(r.out.g, x5.g, r.N, x5.C, x5.H, x5.W, x5.sN, x5.sC, x5.sH, stream);
+            break;
+        }
+        case TK_SQUEEZE: {
+            // 1x1 conv 2c->1 + BatchNorm(1) + ReLU (lib/layers.py:112): out is the 1-channel image z
+            LSTMMod& M = *r.M;
+            bwd_bn_of(r.out, M.squeeze);
+            const Tensor& h = r.srcs[0].t;
+            float* part = ws.allocf((size_t)thin_wgrad_blocks(h) * h.C);
+            if (!dry) {
+                launch_thin_wgrad(h, 1, r.out.g, part, grad_of(M.squeeze.w), 1, stream);
+                launch_thin_dgrad(h, 1, M.squeeze.w->dev, r.out.g, h.g, 1, stream);
+            }
+            break;
+        }
+        case TK_LSTM: {
+            LSTMMod& M = *r.M;
+            const int H = M.hid, G = 4 * H, T = r.out.W, N = r.N;
+            if (!dry) {
+                launch_bilstm_bwd(r.out.g, r.save, M.whh_f->dev, M.whh_r->dev, r.aux.g, N, T, H, stream);
+                launch_lstm_whh_grad(r.aux.g, r.out.p, grad_of(M.whh_f), grad_of(M.whh_r), N, T, H, 1, stream);
+                // b_ih and b_hh enter the gates as a sum: both receive the channel sums of dgx
+                float* tmp = ws.allocf((size_t)2 * G);
+                launch_channel_sum(r.aux.g, N, 2 * G, T, tmp, 0, stream);
+                launch_add(grad_of(M.b_ih_f), tmp, grad_of(M.b_ih_f), G, stream);
+                launch_add(grad_of(M.b_hh_f), tmp, grad_of(M.b_hh_f), G, stream);
+                launch_add(grad_of(M.b_ih_r), tmp + G, grad_of(M.b_ih_r), G, stream);
+                launch_add(grad_of(M.b_hh_r), tmp + G, grad_of(M.b_hh_r), G, stream);
+            } else {
+                ws.allocf((size_t)2 * G);
+            }
+            break;
+        }
+        default:
+            break;
+        }
+    }
+}
+
+void Model::train_fwd_bwd_api(const float* X, const float* Y, bool on_dev, int B, int T, int accumulation_steps,
+                              float* loss_out, float* mask_out, bool mask_on_dev) {
+    VR_HIP(hipSetDevice(device));
+    VR_CHECK(training, -2, "train step needs train mode: call vr_set_mode(h, 1) (model.train(), train.py:69)");
+    VR_CHECK(B > 0 && accumulation_steps > 0, -2, "batch and accumulation_steps must be positive");
+    VR_CHECK(T > 0 && T % 16 == 0, -5, "h1_shape[3] must be greater than h2_shape[3] (frames must be a multiple of 16)");
+    ensure_train_state();
+    const size_t io_floats = (size_t)B * 2 * output_bin * T;
+    const int Hm = max_bin;
+    // ---- plan: dry run of forward + backward sizes both arenas ----------------------------------------
+    auto run_all = [&](const float* xd, const float* yd, float* maskd, float* lossd) {
+        tape.clear();
+        Tensor xt;
+        xt.p = const_cast<float*>(xd); xt.N = B; xt.C = 2; xt.H = Hm; xt.W = T;
+        xt.sH = T; xt.sC = (long long)output_bin * T; xt.sN = 2 * xt.sC; xt.slope = 1.f;
+        Tensor f3 = run_net(xt);
+        // head + loss (train.py:81,89) and its backward into f3.g / out.weight
+        float* dlogit = ws.allocf((size_t)B * 2 * Hm * T);
+        float* lpart = ws.allocf((size_t)head_loss_blocks(f3));
+        float* wpart = ws.allocf((size_t)thin_wgrad_blocks(f3) * 2 * f3.C);
+        if (!dry) {
+            const double ntot = (double)B * 2 * output_bin * T;
+            launch_head_loss(f3, out_w->dev, xd, yd, output_bin, (float)(1.0 / (ntot * accumulation_steps)), dlogit, maskd,
+                             lpart, lossd, (float)(1.0 / ntot), stream);
+            launch_thin_wgrad(f3, 2, dlogit, wpart, grad_of(out_w), 1, stream);
+            launch_thin_dgrad(f3, 2, out_w->dev, dlogit, f3.g, 1, stream);
+        }
+        backward();
+    };
+    {
+        Arena sws = ws, sgs = gs;
+        ws.dry = gs.dry = true; ws.base = gs.base = nullptr; ws.off = gs.off = 0; ws.peak = gs.peak = 0;
+        dry = true;
+        try { run_all(reinterpret_cast<float*>(uintptr_t(256)), nullptr, nullptr, nullptr); }
+        catch (...) { dry = false; ws = sws; gs = sgs; tape.clear(); throw; }
+        dry = false;
+        const size_t need_ws = ws.peak + (3 * io_floats + 64) * sizeof(float) + 8192, need_gs = gs.peak + 4096;
+        ws = sws; gs = sgs;
+        ensure_ws(need_ws);
+        if (need_gs > gs.cap) {
+            VR_HIP(hipStreamSynchronize(stream));
+            if (gs.base) VR_HIP(hipFree(gs.base));
+            gs.base = nullptr; gs.cap = 0;
+            VR_HIP(hipMalloc(reinterpret_cast<void**>(&gs.base), need_gs + (need_gs >> 4)));
+            gs.cap = need_gs + (need_gs >> 4);
+        }
+        ws.reset(); gs.reset();
+        VR_HIP(hipMemsetAsync(gs.base, 0, need_gs, stream));
+    }
+    // ---- dropout keep-masks (lib/layers.py:90: Dropout2d(0.1) on the five ASPP outputs) ----------------------
+    dropout_dev = nullptr;
+    if (dropout_mode != 0) {
+        const size_t n = (size_t)5 * B * 8 * nout;
+        std::vector<float> host(n, 0.f);
+        if (dropout_mode == 2) {
+            VR_CHECK(dropout_host.size() == n, -2, "injected dropout masks were given for a different batch size");
+            host = dropout_host;
+        } else {
+            std::mt19937_64 rng(dropout_seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(adam_step + 1));
+            std::uniform_real_distribution<float> u(0.f, 1.f);
+            for (auto& v : host) v = (u(rng) >= 0.1f) ? 1.f / 0.9f : 0.f;
+        }
+        if (n > dropout_cap) {
+            if (dropout_buf) VR_HIP(hipFree(dropout_buf));
+            VR_HIP(hipMalloc(&dropout_buf, n * sizeof(float)));
+            dropout_cap = n;
+        }
+        VR_HIP(hipMemcpyAsync(dropout_buf, host.data(), n * sizeof(float), hipMemcpyHostToDevice, stream));
+        VR_HIP(hipStreamSynchronize(stream));      // `host` dies with this scope
+        dropout_dev = dropout_buf;
+    }
+    // ---- inputs ---------------------------------------------------------------------------------------------------
+    const float *xd = X, *yd = Y;
+    if (!on_dev) {
+        float* tx = ws.allocf(io_floats);
+        float* ty = ws.allocf(io_floats);
+        VR_HIP(hipMemcpyAsync(tx, X, io_floats * sizeof(float), hipMemcpyHostToDevice, stream));
+        VR_HIP(hipMemcpyAsync(ty, Y, io_floats * sizeof(float), hipMemcpyHostToDevice, stream));
+        xd = tx; yd = ty;
+    }
+    float* maskd = nullptr;
+    if (mask_out) maskd = mask_on_dev ? mask_out : ws.allocf(io_floats);
+    float* lossd = ws.allocf(16);
+    launch_flip_transpose(d_flip, n_flip, stream);
+    run_all(xd, yd, maskd, lossd);
+    float loss_h = 0.f;
+    VR_HIP(hipMemcpyAsync(&loss_h, lossd, sizeof(float), hipMemcpyDeviceToHost, stream));
+    if (mask_out && !mask_on_dev) VR_HIP(hipMemcpyAsync(mask_out, maskd, io_floats * sizeof(float), hipMemcpyDeviceToHost, stream));
+    VR_HIP(hipStreamSynchronize(stream));
+    if (loss_out) *loss_out = loss_h;
+    tape.clear();
+    affine_dirty = true;
+    dropout_dev = nullptr;
+}
+
+void Model::adam_step_api(float lr, float b1, float b2, float eps, float grad_scale) {
+    VR_HIP(hipSetDevice(device));
+    ensure_train_state();
+    adam_step += 1;
+    launch_adam(p_arena, g_arena, m_arena, v_arena, (long long)p_floats, lr, b1, b2, eps, adam_step, grad_scale, stream);
+    VR_HIP(hipStreamSynchronize(stream));
+    affine_dirty = true;
+}
+
+void Model::get_grad(const std::string& key, float* host, int64_t cap_bytes) {
+    auto it = by_key.find(key);
+    VR_CHECK(it != by_key.end(), -2, "unknown parameter key: " + key);
+    Param& p = *it->second;
+    VR_CHECK(p.trainable, -2, key + " is a buffer, it has no gradient");
+    VR_HIP(hipSetDevice(device));
+    ensure_train_state();
+    VR_HIP(hipStreamSynchronize(stream));
+    VR_CHECK((size_t)cap_bytes >= p.numel * sizeof(float), -2, "buffer too small for " + key);
+    const float* g = g_arena + (p.dev - p_arena);
+    if (p.kind == PK_CONV) {
+        std::vector<float> tmp((size_t)p.Cin * p.KK * p.CoutPad);
+        VR_HIP(hipMemcpy(tmp.data(), g, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (int co = 0; co < p.Cout; ++co)
+            for (int ci = 0; ci < p.Cin; ++ci)
+                for (int k = 0; k < p.KK; ++k)
+                    host[((size_t)co * p.Cin + ci) * p.KK + k] = tmp[((size_t)ci * p.KK + k) * p.CoutPad + co];
+    } else if (p.kind == PK_LSTM_IH) {
+        std::vector<float> tmp((size_t)p.Cin * p.Cout);
+        VR_HIP(hipMemcpy2D(tmp.data(), (size_t)p.Cout * sizeof(float), g + p.co_off, (size_t)p.CoutPad * sizeof(float),
+                           (size_t)p.Cout * sizeof(float), (size_t)p.Cin, hipMemcpyDeviceToHost));
+        for (int co = 0; co < p.Cout; ++co)
+            for (int ci = 0; ci < p.Cin; ++ci) host[(size_t)co * p.Cin + ci] = tmp[(size_t)ci * p.Cout + co];
+    } else {
+        VR_HIP(hipMemcpy(host, g, p.numel * sizeof(float), hipMemcpyDeviceToHost));
+    }
+}
+
+}  // namespace vr
+
+// =====================================================================================================
+// unit-test hook: backward of ONE conv (no BatchNorm) through the MFMA dgrad / wgrad kernels
+// =====================================================================================================
+namespace vr {
+
+void Model::debug_conv_bwd(const float* x, int N, int Cin, int H, int W, const float* w_oihw, int Cout, int KS, int stride,
+                           int dh, int dw, int up, const float* aff, float slope, const float* dz, float* dx_out,
+                           float* dw_out) {
+    VR_HIP(hipSetDevice(device));
+    ensure_train_state();
+    const int KK = KS * KS, CoutPad = (Cout + 31) / 32 * 32, CinPad = round_up32(Cin);
+    Conv L;
+    L.name = "debug"; L.Cin = Cin; L.Cout = Cout; L.CoutPad = CoutPad; L.KS = KS; L.stride = stride; L.dh = dh; L.dw = dw;
+    L.pad_h = KS == 1 ? 0 : dh; L.pad_w = KS == 1 ? 0 : dw; L.bn = nullptr; L.slope = 1.f;
+    Param P;
+    P.kind = PK_CONV; P.Cin = Cin; P.Cout = Cout; P.KK = KK; P.CoutPad = CoutPad;
+    L.w = &P;
+    const int Hin = up ? 2 * H : H, Win = up ? 2 * W : W;
+    const int Hout = (Hin + 2 * L.pad_h - dh * (KS - 1) - 1) / stride + 1, Wout = (Win + 2 * L.pad_w - dw * (KS - 1) - 1) / stride + 1;
+    std::vector<float> wk((size_t)Cin * KK * CoutPad, 0.f);
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int k = 0; k < KK; ++k) wk[((size_t)ci * KK + k) * CoutPad + co] = w_oihw[((size_t)co * Cin + ci) * KK + k];
+    const size_t xin = (size_t)N * Cin * H * W, xout = (size_t)N * Cout * Hout * Wout;
+    float *dx, *dgx, *dwk, *dwt, *dgw, *dzd, *daff = nullptr;
+    VR_HIP(hipMalloc(&dx, xin * 4)); VR_HIP(hipMalloc(&dgx, xin * 4)); VR_HIP(hipMalloc(&dwk, wk.size() * 4));
+    VR_HIP(hipMalloc(&dwt, (size_t)Cout * KK * CinPad * 4)); VR_HIP(hipMalloc(&dgw, wk.size() * 4)); VR_HIP(hipMalloc(&dzd, xout * 4));
+    VR_HIP(hipMemcpy(dx, x, xin * 4, hipMemcpyHostToDevice));
+    VR_HIP(hipMemset(dgx, 0, xin * 4)); VR_HIP(hipMemset(dgw, 0, wk.size() * 4)); VR_HIP(hipMemset(dwt, 0, (size_t)Cout * KK * CinPad * 4));
+    VR_HIP(hipMemcpy(dwk, wk.data(), wk.size() * 4, hipMemcpyHostToDevice));
+    VR_HIP(hipMemcpy(dzd, dz, xout * 4, hipMemcpyHostToDevice));
+    if (aff) { VR_HIP(hipMalloc(&daff, (size_t)Cin * 8)); VR_HIP(hipMemcpy(daff, aff, (size_t)Cin * 8, hipMemcpyHostToDevice)); }
+    P.dev = dwk; P.grad_override = dgw;
+    wt_of[&P] = dwt;
+    FlipDesc fd{dwk, dwt, Cin, Cout, KK, CinPad, CoutPad};
+    FlipDesc* dfd;
+    VR_HIP(hipMalloc(&dfd, sizeof(FlipDesc)));
+    VR_HIP(hipMemcpy(dfd, &fd, sizeof(FlipDesc), hipMemcpyHostToDevice));
+    launch_flip_transpose(dfd, 1, stream);
+    Tensor t;
+    t.p = dx; t.g = dgx; t.N = N; t.C = Cin; t.H = H; t.W = W; t.sH = W; t.sC = (long long)H * W; t.sN = t.sC * Cin;
+    t.aff0 = daff; t.slope = slope;
+    TapeRec r;
+    r.kind = TK_CONV; r.L = &L; r.N = N;
+    SrcSpec sp{t}; sp.up = up != 0;
+    r.srcs = {sp};
+    r.out.p = nullptr; r.out.g = dzd; r.out.N = N; r.out.C = Cout; r.out.H = Hout; r.out.W = Wout;
+    r.out.sH = Wout; r.out.sC = (long long)Hout * Wout; r.out.sN = r.out.sC * Cout; r.out.slope = 1.f;
+    {   // size the workspace with a dry pass
+        Arena sws = ws;
+        ws.dry = true; ws.base = nullptr; ws.off = 0; ws.peak = 0; dry = true;
+        try { bwd_conv(r); } catch (...) { dry = false; ws = sws; throw; }
+        dry = false;
+        const size_t need = ws.peak + 4096;
+        ws = sws;
+        ensure_ws(need);
+        ws.reset();
+    }
+    bwd_conv(r);
+    VR_HIP(hipStreamSynchronize(stream));
+    VR_HIP(hipMemcpy(dx_out, dgx, xin * 4, hipMemcpyDeviceToHost));
+    std::vector<float> gk(wk.size());
+    VR_HIP(hipMemcpy(gk.data(), dgw, gk.size() * 4, hipMemcpyDeviceToHost));
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int k = 0; k < KK; ++k) dw_out[((size_t)co * Cin + ci) * KK + k] = gk[((size_t)ci * KK + k) * CoutPad + co];
+    wt_of.erase(&P);
+    hipFree(dx); hipFree(dgx); hipFree(dwk); hipFree(dwt); hipFree(dgw); hipFree(dzd); hipFree(daff); hipFree(dfd);
+}
+
+}  // namespace vr

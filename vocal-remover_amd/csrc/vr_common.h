@@ -55,6 +55,7 @@ struct Tensor {
     int hsplit = 1 << 30;
     float slope = 1.f;
     const float* post = nullptr;   // [N][C] post-activation multiplier (Dropout2d), or null
+    float* g = nullptr;            // training: gradient w.r.t. the value consumers see (same strides as p)
 };
 
 // One input of a (virtually concatenated) convolution.
@@ -69,6 +70,16 @@ struct ConvSrc {
     int up;            // 1: bilinear x2, align_corners=True (lib/layers.py:52), fused into the load
     float rh, rw;      // (H-1)/(2H-1), (W-1)/(2W-1) as torch's area_pixel_compute_scale<float>
     const float* post; // [N][C] multiplier applied after the activation (Dropout2d keep-mask / 0.9), or null
+    int zins;          // 1: the source occupies the even virtual coordinates, zeros in between
+                       //    (data-gradient of a stride-2 conv = stride-1 conv over the zero-inserted gradient)
+};
+
+// One output segment of a conv launch (the data-gradient of a virtually concatenated input is
+// split back to the tensors it came from).
+struct ConvDst {
+    float* p;                  // null: channels of this segment are not stored (e.g. grad of the network input)
+    long long sN, sC, sH;
+    int accumulate;            // 1: += (gradient accumulation over several consumers)
 };
 
 struct ConvArgs {
@@ -78,8 +89,8 @@ struct ConvArgs {
     const float* w;            // [Cin][KS*KS][CoutPad]  (K-major, cout contiguous)
     const float* bias;         // [Cout] or null
     int Cout, CoutPad;
-    float* out;
-    long long oN, oC, oH;
+    ConvDst dst[3];
+    int d1, d2;                // dst0 = output channels [0,d1), dst1 = [d1,d2), dst2 = [d2,Cout)
     float* part;               // per-block BatchNorm partials [npt][Cout][2] (sum, sumsq) or null
     int N, Hout, Wout, Hin, Win;
     int pad_h, pad_w;
@@ -89,6 +100,20 @@ struct ConvArgs {
 struct ConvShape {             // static description used by the launcher
     int KS, stride, dil_h, dil_w;
 };
+
+// Weight-gradient launch (wgrad_mfma.hip): `in` describes the conv's virtual input exactly like the
+// forward launch (its Hout/Wout are the dims of dz); dz is the gradient at the raw conv output.
+struct WgradArgs {
+    ConvArgs in;
+    const float* dz;
+    long long zN, zC, zH;
+    int Cout, CoutPad;
+    float* part;               // scratch [P][Cin][KS*KS][CoutPad]
+    long long part_stride;
+    int P, tiles_w, tiles_h, npt, nchunks, nct;
+};
+double launch_wgrad(const WgradArgs& a, const ConvShape& s, float* grad_out, int accumulate, hipStream_t st);
+size_t wgrad_scratch_floats(const WgradArgs& a, const ConvShape& s);
 
 // Returns the algorithmic FLOPs of the launch (2*MACs) for roofline accounting.
 double launch_conv(const ConvArgs& a, const ConvShape& s, hipStream_t st);

@@ -1,0 +1,232 @@
+// Weight gradient of every conv of the hot path (backward of lib/layers.py:12-20 under train.py:92):
+//   dW[co][ci][kh][kw] = sum_{n,h,w} dz[n][co][h][w] * in[n][ci][h*s + kh*d - pad][w*s + kw*d - pad]
+// as an fp32-MFMA GEMM with the reduction over PIXELS:  D[i=co][j=ci] += A[i][k=pixel] * B[k][j]
+// (one 32x32 accumulator tile per (32-cout block, tap)).  `in` is the conv's virtual input, staged
+// through the same fused loader as the forward pass (concat / upsample / BatchNorm affine /
+// activation / dropout re-applied on the fly from the RAW saved tensors), `dz` is the gradient at the
+// conv's raw output (already through the BatchNorm backward).
+//
+// Work split: block = (32 input channels, MB*32 output channels, one of P contiguous ranges of
+// pixel tiles); accumulators live in registers across the whole pixel range, then one partial
+// [ci][tap][co] slab per block goes to scratch and `wgrad_reduce_kernel` sums the P slabs
+// (deterministic; no atomics).
+#include "conv_stage.h"
+#include "kernels.h"
+
+namespace vr {
+
+template <int KS, int S, int DH, int DW, int TH, int TW, int MB>
+struct WgCfg {
+    static constexpr int KK = KS * KS;
+    static constexpr int TP = TH * TW;                 // pixels per tile (= MFMA K extent per tile)
+    static constexpr int TH_in = (TH - 1) * S + (KS - 1) * DH + 1;
+    static constexpr int TW_in = (TW - 1) * S + (KS - 1) * DW + 1;
+    static constexpr int CS = (TH_in * TW_in) | 1;     // odd channel pitch: 32 lanes = 32 channels -> 32 banks
+    static constexpr int DSs = TP + 1;                 // odd cout pitch
+    static constexpr int NT = (KK * MB + 3) / 4;       // accumulator tiles per wave
+    static constexpr int XS = 32 * CS;
+    static constexpr int DS = MB * 32 * DSs;
+    static constexpr int LDS_BYTES = (XS + DS) * 4;
+};
+
+template <int KS, int S, int DH, int DW, int TH, int TW, int MB>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradArgs a) {
+    using Cfg = WgCfg<KS, S, DH, DW, TH, TW, MB>;
+    constexpr int KK = Cfg::KK, TP = Cfg::TP, TH_in = Cfg::TH_in, TW_in = Cfg::TW_in, CS = Cfg::CS, DSs = Cfg::DSs,
+                  NT = Cfg::NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;
+    float* Ds = smem + Cfg::XS;
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int rr = id >> 3;
+    const int inner = a.nchunks * a.nct;
+    const int p = (rr / inner) * 8 + xcd;
+    if (p >= a.P) return;
+    const int ib = rr % inner;
+    const int ct = ib % a.nct, cb = ib / a.nct;
+    const int co0 = ct * MB * 32, c0 = cb * 32;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int khalf = lane >> 5, l31 = lane & 31;
+
+    int mb_i[NT], tap_i[NT], moff_i[NT], toff_i[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        int t = wave + 4 * i;
+        t = t < KK * MB ? t : KK * MB - 1;      // surplus slots recompute the last tile, never stored
+        mb_i[i] = t / KK;
+        tap_i[i] = t % KK;
+        moff_i[i] = mb_i[i] * 32 * DSs;
+        toff_i[i] = (tap_i[i] / KS) * DH * TW_in + (tap_i[i] % KS) * DW;
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    const int tiles_per_img = a.tiles_h * a.tiles_w;
+    const int t_begin = (int)((long long)p * a.npt / a.P), t_end = (int)((long long)(p + 1) * a.npt / a.P);
+    for (int pt = t_begin; pt < t_end; ++pt) {
+        const int n = pt / tiles_per_img;
+        const int trem = pt - n * tiles_per_img;
+        const int h0 = (trem / a.tiles_w) * TH, w0 = (trem % a.tiles_w) * TW;
+        __syncthreads();
+        // ---- dz tile: Ds[co][px] ------------------------------------------------------------------
+        {
+            constexpr int NEL = MB * 32 * TP;
+            constexpr int NPASS = NEL / 256;
+            constexpr int PB = NPASS < 8 ? NPASS : 8;
+            const float* zb = a.dz + (long long)n * a.zN;
+#pragma unroll 1
+            for (int p0 = 0; p0 < NPASS; p0 += PB) {
+                float v[PB];
+#pragma unroll
+                for (int j = 0; j < PB; ++j) {
+                    const int idx = tid + (p0 + j) * 256;
+                    const int co = idx / TP, px = idx % TP;
+                    int cg = co0 + co; cg = cg < a.Cout ? cg : a.Cout - 1;
+                    int h = h0 + px / TW, w = w0 + px % TW;
+                    h = h < a.in.Hout ? h : a.in.Hout - 1;
+                    w = w < a.in.Wout ? w : a.in.Wout - 1;
+                    v[j] = zb[(long long)cg * a.zC + (long long)h * a.zH + w];
+                }
+#pragma unroll
+                for (int j = 0; j < PB; ++j) {
+                    const int idx = tid + (p0 + j) * 256;
+                    const int co = idx / TP, px = idx % TP;
+                    const bool ok = (co0 + co < a.Cout) && (h0 + px / TW < a.in.Hout) && (w0 + px % TW < a.in.Wout);
+                    Ds[co * DSs + px] = ok ? v[j] : 0.f;
+                }
+            }
+        }
+        // ---- input tile: Xs[ci][haloed tile] -------------------------------------------------------------
+        stage_input_chunk<TH_in, TW_in, TW_in, CS, 32, 4>(a.in, Xs, c0, n, h0 * S - a.in.pad_h, w0 * S - a.in.pad_w,
+                                                           wave, lane);
+        __syncthreads();
+        // ---- MFMA over the tile's pixels ---------------------------------------------------------------------
+#pragma unroll 2
+        for (int kp = 0; kp < TP / 2; ++kp) {
+            const int px = 2 * kp + khalf;
+            const int r = px / TW, c = px % TW;
+            const int xoff = l31 * CS + (r * S) * TW_in + c * S;
+            const int doff = l31 * DSs + px;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const float av = Ds[moff_i[i] + doff];
+                const float bv = Xs[xoff + toff_i[i]];
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i], 0, 0, 0);
+            }
+        }
+    }
+    // ---- partial slab: part[p][ci][tap][co] ----------------------------------------------------------------------
+    float* pp = a.part + (long long)p * a.part_stride;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        if (wave + 4 * i >= KK * MB) continue;
+        const int ci = c0 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + mb_i[i] * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            if (ci < a.in.Cin && co < a.CoutPad) pp[((long long)ci * KK + tap_i[i]) * a.CoutPad + co] = acc[i][r];
+        }
+    }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, long long stride, int P, float* __restrict__ out,
+                                    long long n, int accumulate) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += part[p * stride + i];
+    out[i] = accumulate ? out[i] + s : s;
+}
+
+struct WgTile { int TH, TW, MB; };
+
+static WgTile wg_pick(const WgradArgs& a, const ConvShape& s) {
+    WgTile t;
+    const bool dilated = (s.dil_h != 1 || s.dil_w != 1);
+    t.TW = (a.in.Wout >= 32 && !dilated) ? 32 : 16;
+    t.TH = dilated ? 4 : (t.TW == 32 ? 4 : 8);
+    const int nb = a.CoutPad / 32;
+    t.MB = (nb % 4 == 0) ? 4 : ((nb % 2 == 0) ? 2 : 1);
+    return t;
+}
+
+void wgrad_plan(WgradArgs& a, const ConvShape& s) {
+    const WgTile t = wg_pick(a, s);
+    a.tiles_w = (a.in.Wout + t.TW - 1) / t.TW;
+    a.tiles_h = (a.in.Hout + t.TH - 1) / t.TH;
+    a.npt = a.in.N * a.tiles_h * a.tiles_w;
+    a.nchunks = (a.in.Cin + 31) / 32;
+    a.nct = a.CoutPad / (32 * t.MB);
+    a.part_stride = (long long)a.in.Cin * s.KS * s.KS * a.CoutPad;
+    long long P = 1024 / ((long long)a.nchunks * a.nct);
+    if (P < 1) P = 1;
+    if (P > a.npt) P = a.npt;
+    const long long cap = (64LL << 20) / a.part_stride;       // scratch <= 256 MB
+    if (P > cap) P = cap < 1 ? 1 : cap;
+    a.P = (int)P;
+}
+
+template <int KS, int S, int DH, int DW, int TH, int TW, int MB>
+static void wg_launch_inst(const WgradArgs& a, hipStream_t st) {
+    using Cfg = WgCfg<KS, S, DH, DW, TH, TW, MB>;
+    auto kern = wgrad_mfma_kernel<KS, S, DH, DW, TH, TW, MB>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   Cfg::LDS_BYTES));
+        attr_set = true;
+    }
+    const int grid = ((a.P + 7) / 8) * 8 * a.nchunks * a.nct;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::LDS_BYTES, st, a);
+    VR_HIP(hipGetLastError());
+}
+
+template <int KS, int S, int DH, int DW, int TH, int TW>
+static void wg_launch_mb(const WgradArgs& a, int MB, hipStream_t st) {
+    if (MB == 4) wg_launch_inst<KS, S, DH, DW, TH, TW, 4>(a, st);
+    else if (MB == 2) wg_launch_inst<KS, S, DH, DW, TH, TW, 2>(a, st);
+    else wg_launch_inst<KS, S, DH, DW, TH, TW, 1>(a, st);
+}
+
+double launch_wgrad(const WgradArgs& a_in, const ConvShape& s, float* grad_out, int accumulate, hipStream_t st) {
+    WgradArgs a = a_in;
+    wgrad_plan(a, s);
+    const WgTile t = wg_pick(a, s);
+    VR_CHECK(a.part != nullptr, -2, "wgrad needs a scratch slab");
+    if (s.KS == 1) {
+        if (t.TW == 32) wg_launch_mb<1, 1, 1, 1, 4, 32>(a, t.MB, st); else wg_launch_mb<1, 1, 1, 1, 8, 16>(a, t.MB, st);
+    } else if (s.stride == 1 && s.dil_h == 1 && s.dil_w == 1) {
+        if (t.TW == 32) wg_launch_mb<3, 1, 1, 1, 4, 32>(a, t.MB, st); else wg_launch_mb<3, 1, 1, 1, 8, 16>(a, t.MB, st);
+    } else if (s.stride == 2) {
+        if (t.TW == 32) wg_launch_mb<3, 2, 1, 1, 4, 32>(a, t.MB, st); else wg_launch_mb<3, 2, 1, 1, 8, 16>(a, t.MB, st);
+    } else if (s.dil_h == 4 && s.dil_w == 2) {
+        wg_launch_mb<3, 1, 4, 2, 4, 16>(a, t.MB, st);
+    } else if (s.dil_h == 8 && s.dil_w == 4) {
+        wg_launch_mb<3, 1, 8, 4, 4, 16>(a, t.MB, st);
+    } else if (s.dil_h == 12 && s.dil_w == 6) {
+        wg_launch_mb<3, 1, 12, 6, 4, 16>(a, t.MB, st);
+    } else {
+        throw Error(-2, "unsupported wgrad shape");
+    }
+    const long long n = a.part_stride;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.part, a.part_stride,
+                       a.P, grad_out, n, accumulate);
+    VR_HIP(hipGetLastError());
+    return 2.0 * a.in.N * (double)a.in.Hout * a.in.Wout * (double)a.Cout * a.in.Cin * s.KS * s.KS;
+}
+
+size_t wgrad_scratch_floats(const WgradArgs& a_in, const ConvShape& s) {
+    WgradArgs a = a_in;
+    wgrad_plan(a, s);
+    return (size_t)a.P * (size_t)a.part_stride;
+}
+
+}  // namespace vr

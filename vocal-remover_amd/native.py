@@ -30,11 +30,20 @@ _SIGNATURES = {
                                    ctypes.c_int, c_f32p, c_f32p, ctypes.c_int]),
     'vr_separate_wave': (ctypes.c_int, [ctypes.c_void_p, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
                                         ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, ctypes.c_int]),
+    'vr_train_step': (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, ctypes.POINTER(ctypes.c_float), c_f32p, ctypes.c_int]),
+    'vr_adam_step': (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_float] * 5),
+    'vr_zero_grad': (ctypes.c_int, [ctypes.c_void_p]),
+    'vr_get_grad': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_f32p, ctypes.c_int64]),
+    'vr_set_dropout': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, c_f32p, ctypes.c_int]),
+    'vr_grad_arena': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64)]),
     'vr_profile_begin': (ctypes.c_int, [ctypes.c_void_p]),
     'vr_profile_end': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
                                       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
     'vr_debug_conv2d': (ctypes.c_int, [ctypes.c_void_p, c_f32p] + [ctypes.c_int] * 4 + [c_f32p] + [ctypes.c_int] * 6
                         + [c_f32p, ctypes.c_float, c_f32p, c_f32p, c_f32p]),
+    'vr_debug_conv2d_backward': (ctypes.c_int, [ctypes.c_void_p, c_f32p] + [ctypes.c_int] * 4 + [c_f32p]
+                                 + [ctypes.c_int] * 6 + [c_f32p, ctypes.c_float, c_f32p, c_f32p, c_f32p]),
     'vr_debug_record_taps': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'vr_debug_get_tap': (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p, c_f32p, ctypes.c_int64, c_i64p]),
 }

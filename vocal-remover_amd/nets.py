@@ -214,6 +214,75 @@ class CascadedNet(object):
         """CascadedNet.predict (lib/nets.py:133-141): (x * mask)[..., 64:-64]."""
         return self._run(x, 2)
 
+    # ---- training (train.py:77-96) ----------------------------------------------------------------------
+    def parameters(self):
+        """Stands in for nn.Module.parameters(): one reference to the native parameter arena, accepted
+        by vocal_remover_amd.train.Adam (the reference filters on .requires_grad, train.py:216)."""
+        from .train import _ParamRef
+        return [_ParamRef(self)]
+
+    def zero_grad(self):
+        if self._handle is not None:
+            native.check(native.lib().vr_zero_grad(self._handle.h))
+
+    def train_step(self, X, y, accumulation_steps=1, return_mask=False):
+        """mask = model(X); loss = L1Loss()(mask * X, y); (loss / accumulation_steps).backward()
+        in one native call.  Returns loss.item() (and the mask if asked)."""
+        import ctypes
+        h = self._need_handle()
+        X = torch.as_tensor(X)
+        y = torch.as_tensor(y)
+        if X.shape != y.shape or X.dim() != 4 or X.shape[1] != 2 or X.shape[2] != self.output_bin:
+            raise ValueError('expected X, y of shape [B, 2, %d, T]' % self.output_bin)
+        on_dev = X.is_cuda
+        if on_dev != y.is_cuda:
+            raise ValueError('X and y must live on the same device')
+        X = X.detach().to(torch.float32).contiguous()
+        y = y.detach().to(torch.float32).contiguous()
+        B, T = int(X.shape[0]), int(X.shape[3])
+        mask = torch.empty_like(X) if return_mask else None
+        if on_dev:
+            torch.cuda.current_stream(X.device).synchronize()
+        loss = ctypes.c_float()
+        native.check(native.lib().vr_train_step(h.h, X.data_ptr(), y.data_ptr(), int(on_dev), B, T,
+                                                int(accumulation_steps), ctypes.byref(loss),
+                                                mask.data_ptr() if return_mask else None, int(on_dev)))
+        self._host_stale = True
+        return (loss.value, mask) if return_mask else loss.value
+
+    def grads(self, keys=None):
+        """{key: gradient} in torch layouts (param.grad of the reference), for tests."""
+        h = self._need_handle()
+        out = OrderedDict()
+        for k, shape, init in self._spec:
+            if init == 'nbt' or k.endswith('running_mean') or k.endswith('running_var'):
+                continue
+            if keys is not None and k not in keys:
+                continue
+            arr = np.empty(shape, dtype=np.float32)
+            native.check(native.lib().vr_get_grad(h.h, k.encode(), native.np_ptr(arr), arr.nbytes))
+            out[k] = torch.from_numpy(arr)
+        return out
+
+    def set_dropout_masks(self, masks):
+        """Inject Dropout2d keep-masks {'<net>.aspp': [B, 8c] tensor of 0 / (1/0.9)} (parity tests);
+        None switches dropout off; an int seeds the library's own RNG."""
+        h = self._need_handle()
+        if masks is None:
+            native.check(native.lib().vr_set_dropout(h.h, 0, 0, None, 0))
+            return
+        if isinstance(masks, int):
+            native.check(native.lib().vr_set_dropout(h.h, 1, masks, None, 0))
+            return
+        order = ['stg1_low_band_net.0', 'stg1_high_band_net', 'stg2_low_band_net.0', 'stg2_high_band_net',
+                 'stg3_full_band_net']
+        B = int(next(iter(masks.values())).shape[0])
+        buf = np.zeros((5, B * 8 * self.nout), dtype=np.float32)
+        for i, name in enumerate(order):
+            m = masks[name + '.aspp'].to(torch.float32).contiguous().numpy().reshape(-1)
+            buf[i, :m.size] = m
+        native.check(native.lib().vr_set_dropout(h.h, 2, 0, native.np_ptr(buf), B))
+
     # ---- host <-> device weights ----------------------------------------------------------------------
     def _push(self):
         if self._handle is None:
