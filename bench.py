@@ -188,6 +188,13 @@ def main():
     nat.check(nat.lib().vr_profile_end(net._handle.h, ctypes.byref(cms), ctypes.byref(cfl), ctypes.byref(cn)))
     achieved = cfl.value / (cms.value * 1e-3) / 1e12 if cms.value > 0 else 0.0
 
+    # HBM traffic of the dominant kernel: rocprofv3 PMC passes of this same command (collected
+    # separately -- counters cannot be read from inside the process), summary committed in profiles/
+    traffic = None
+    pmc_path = os.path.join(ROOT, 'profiles', 'r01_infer_pmc.json')
+    if args.mode == 'infer' and not args.tta and args.seconds == 30.0 and os.path.exists(pmc_path):
+        traffic = json.load(open(pmc_path)).get('bytes_per_launch')
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         out = {
@@ -204,7 +211,10 @@ def main():
                        else 'dp%d (RCCL all-reduce of one flat fp32 gradient bucket)' % world},
             'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel<*> (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM conv)',
                          'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                         'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
+                         'traffic_unit': 'HBM bytes per launch (mean over the conv launches of a step; rocprofv3 '
+                                         'FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/r01_infer_pmc.json)',
+                         'algorithmic_bytes_per_launch': 1.1475e9 * crops / max(cn.value, 1) if args.mode == 'infer' else None,
                          'launches_per_step': cn.value, 'kernel_ms_per_step': cms.value,
                          'algorithmic_gflop_per_step': cfl.value / 1e9},
         }
