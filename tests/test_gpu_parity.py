@@ -193,7 +193,9 @@ def test_batch_independence_full_net(full):
     x = torch.rand(3, 2, 1025, 256, generator=torch.Generator().manual_seed(3)).to('cuda:0')
     all3 = model.predict_mask(x)
     one = model.predict_mask(x[1:2].contiguous())
-    assert float((all3[1:2] - one).abs().max()) < 1e-6
+    # not bit-identical: the launcher picks tile shapes / channel-chunk sizes from the grid size, which
+    # changes the fp32 summation order; anything beyond rounding noise would be cross-crop leakage
+    assert float((all3[1:2] - one).abs().max()) < 1e-5
 
 
 def test_stft_istft_vs_oracle(vr):

@@ -18,6 +18,8 @@
 // fp32 MFMA runs at the fp32 vector rate (157 TFLOP/s peak) but reaches it with one LDS read
 // per operand per 64-cycle instruction, which is what makes a >100 TFLOP/s conv reachable; the
 // VALU stays free for the staging transforms.
+#include <cstdlib>
+
 #include "conv_stage.h"
 
 namespace vr {
@@ -37,7 +39,8 @@ struct ConvCfg {
     static constexpr int TWp = (TW == 16) ? ((TW_in + 15) / 32 * 32 + 16) : ((TW_in + 1) & ~1);
     static constexpr int XS = CK * TH_in * TWp;
     static constexpr int WS = KK * CK * MT;
-    static constexpr int LDS_BYTES = (XS + WS) * 4;
+    static constexpr int STG = StageGeom<TH_in, TW_in>::TAB + StageGeom<TH_in, TW_in>::SCR;   // geometry tables + scratch
+    static constexpr int LDS_BYTES = (XS + WS + STG) * 4;
     static_assert(WM >= 1 && WN >= 1 && WM * WAVES_M * 32 == MT && WN * WAVES_N == NG, "tile split");
     static_assert(XS % 4 == 0, "weight slab must stay 16B aligned");
     static_assert(TWp >= TW_in, "pitch");
@@ -96,60 +99,113 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     const int hbase = h0 * S - a.pad_h;
     const int wbase = w0 * S - a.pad_w;
 
-    for (int c0 = 0; c0 < a.Cin; c0 += CK) {
-        __syncthreads();   // previous chunk's MFMA reads are done
-        // ---------------- stage weights: Ws[tap][cl][m] <- w[(c0+cl)][tap][co0+m] -------------
-        // All loads of a batch are issued before any is consumed (addresses are clamped so the
-        // loads are unconditional): one HBM/L2 round trip per batch instead of one per element.
-        {
-            constexpr int M4 = MT / 4;
-            constexpr int NW = CK * KK * M4;
-            constexpr int WP = (NW + 255) / 256;
-            float4 wv[WP];
+    // ---- software pipeline (issue-early / write-late): the raw global loads of chunk k+1 are in
+    // flight in registers while the MFMAs of chunk k run; the affine/activation/upsample transform
+    // and the LDS writes happen after them.  One LDS buffer, two barriers per chunk.
+    using SG = StageGeom<TH_in, TW_in>;
+    constexpr int M4 = MT / 4;
+    constexpr int NWV = CK * KK * M4;                 // float4 weight vectors per chunk
+    constexpr int WP = (NWV + 255) / 256;
+    constexpr int CPW = (CK + 3) / 4;
+    int* tab = reinterpret_cast<int*>(smem + Cfg::XS + Cfg::WS);
+    float* scratch = smem + Cfg::XS + Cfg::WS + SG::TAB + wave * SG::NL;
+    float4 wv[WP];
+    float raw[(S == 1 && DH == 1 && DW == 1) ? CPW : 1][SG::NPX];
+    auto issue_weights = [&](int c0) {
 #pragma unroll
-            for (int j = 0; j < WP; ++j) {
-                int idx = tid + j * 256;
-                idx = idx < NW ? idx : NW - 1;
+        for (int j = 0; j < WP; ++j) {
+            int idx = tid + j * 256;
+            idx = idx < NWV ? idx : NWV - 1;
+            const int m4 = idx % M4;
+            const int t2 = idx / M4;
+            const int tap = t2 % KK;
+            int ci = c0 + t2 / KK;
+            ci = ci < a.Cin ? ci : a.Cin - 1;
+            wv[j] = *reinterpret_cast<const float4*>(a.w + ((long long)ci * KK + tap) * a.CoutPad + co0 + m4 * 4);
+        }
+    };
+    // Stride-2 and dilated tiles have 3x larger halos (18 load passes per channel): prefetching them
+    // costs ~250 VGPRs, so those variants keep the synchronous staging.
+    constexpr bool PIPE = (S == 1 && DH == 1 && DW == 1);
+    if constexpr (PIPE) {
+        issue_weights(0);
+        build_stage_tables<TH_in, TW_in, TWp>(a, tab, hbase, wbase, tid);
+        __syncthreads();
+        issue_input_loads<TH_in, TW_in, CK, 4>(a, tab, 0, n, wave, lane, raw);
+    }
+
+    for (int c0 = 0; c0 < a.Cin; c0 += CK) {
+        if (a.dbg != 3) __syncthreads();   // previous chunk's MFMA reads are done
+        if constexpr (!PIPE) issue_weights(c0);
+        // ---------------- write stage: Ws[tap][cl][m] <- w[(c0+cl)][tap][co0+m], Xs <- transform(raw) ----
+#pragma unroll
+        for (int j = 0; j < WP; ++j) {
+            const int idx = tid + j * 256;
+            if (idx < NWV) {
                 const int m4 = idx % M4;
                 const int t2 = idx / M4;
                 const int tap = t2 % KK;
-                int ci = c0 + t2 / KK;
-                ci = ci < a.Cin ? ci : a.Cin - 1;
-                wv[j] = *reinterpret_cast<const float4*>(a.w + ((long long)ci * KK + tap) * a.CoutPad + co0 + m4 * 4);
-            }
-#pragma unroll
-            for (int j = 0; j < WP; ++j) {
-                const int idx = tid + j * 256;
-                if (idx < NW) {
-                    const int m4 = idx % M4;
-                    const int t2 = idx / M4;
-                    const int tap = t2 % KK;
-                    const int cl = t2 / KK;
-                    const float4 v = (c0 + cl < a.Cin) ? wv[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    *reinterpret_cast<float4*>(Ws + (tap * CK + cl) * MT + m4 * 4) = v;
-                }
+                const int cl = t2 / KK;
+                const float4 v = (c0 + cl < a.Cin) ? wv[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(Ws + (tap * CK + cl) * MT + m4 * 4) = v;
             }
         }
-        stage_input_chunk<TH_in, TW_in, TWp, TH_in * TWp, CK, 4>(a, Xs, c0, n, hbase, wbase, wave, lane);
-        __syncthreads();
+        if constexpr (PIPE) {
+            if (a.dbg != 1 && a.dbg != 3) write_input_stage<TH_in, TW_in, TH_in * TWp, CK, 4>(a, tab, Xs, scratch, c0, n, wave, lane, raw);
+        } else
+            stage_input_chunk<TH_in, TW_in, TWp, TH_in * TWp, CK, 4>(a, Xs, c0, n, hbase, wbase, wave, lane);
+        if (a.dbg != 3) __syncthreads();
+        // ---------------- prefetch the next chunk (in flight during the MFMAs below) -----------------------
+        // (unconditional: a conditional prefetch turns the register arrays into phi nodes and the
+        // compiler then waits vmcnt(0) right here to copy them; the last iteration re-fetches its own chunk)
+        if constexpr (PIPE) {
+            const int cn = (c0 + CK < a.Cin) ? c0 + CK : c0;
+            if (a.dbg != 1 && a.dbg != 3) {
+                issue_weights(cn);
+                issue_input_loads<TH_in, TW_in, CK, 4>(a, tab, cn, n, wave, lane, raw);
+            }
+        }
         // ---------------- MFMA over this chunk ---------------------------------------------------
         const int cleft = a.Cin - c0;
-        const int npair = ((cleft < CK ? cleft : CK) + 1) >> 1;
+        const int npair = a.dbg == 2 ? 0 : ((cleft < CK ? cleft : CK) + 1) >> 1;
+        if (npair == CK / 2) {
+            // full chunk: fully unrolled so the scheduler can hoist the LDS operand reads of later
+            // (tap, pair) steps above the MFMAs of earlier ones (hides the LDS latency)
 #pragma unroll
-        for (int tap = 0; tap < KK; ++tap) {
-            const int kh = tap / KS, kw = tap % KS;
-            const int toff = kh * DH * TWp + kw * DW;
-            for (int kk = 0; kk < npair; ++kk) {
-                float av[WM], bv[WN];
+            for (int tap = 0; tap < KK; ++tap) {
+                const int kh = tap / KS, kw = tap % KS;
+                const int toff = kh * DH * TWp + kw * DW;
 #pragma unroll
-                for (int mi = 0; mi < WM; ++mi) av[mi] = Ws[(tap * CK + 2 * kk) * MT + aoff + mi * 32];
+                for (int kk = 0; kk < CK / 2; ++kk) {
+                    float av[WM], bv[WN];
 #pragma unroll
-                for (int ni = 0; ni < WN; ++ni) bv[ni] = Xs[2 * kk * TH_in * TWp + toff + boff[ni]];
+                    for (int mi = 0; mi < WM; ++mi) av[mi] = Ws[(tap * CK + 2 * kk) * MT + aoff + mi * 32];
 #pragma unroll
-                for (int mi = 0; mi < WM; ++mi)
+                    for (int ni = 0; ni < WN; ++ni) bv[ni] = Xs[2 * kk * TH_in * TWp + toff + boff[ni]];
 #pragma unroll
-                    for (int ni = 0; ni < WN; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+                    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < WN; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int tap = 0; tap < KK; ++tap) {
+                const int kh = tap / KS, kw = tap % KS;
+                const int toff = kh * DH * TWp + kw * DW;
+                for (int kk = 0; kk < npair; ++kk) {
+                    float av[WM], bv[WN];
+#pragma unroll
+                    for (int mi = 0; mi < WM; ++mi) av[mi] = Ws[(tap * CK + 2 * kk) * MT + aoff + mi * 32];
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni) bv[ni] = Xs[2 * kk * TH_in * TWp + toff + boff[ni]];
+#pragma unroll
+                    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < WN; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+                }
             }
         }
     }
@@ -163,8 +219,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             const int co = co0 + (wm * WM + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
             const float b = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
             const int seg = (co >= a.d1) + (co >= a.d2);
-            const ConvDst& d = a.dst[seg];
             const int cod = co - (seg == 0 ? 0 : (seg == 1 ? a.d1 : a.d2));
+            ConvDst d;      // field-wise select: a dynamic index into the kernarg would go through scratch
+            d.p = seg == 0 ? a.dst[0].p : (seg == 1 ? a.dst[1].p : a.dst[2].p);
+            d.sN = seg == 0 ? a.dst[0].sN : (seg == 1 ? a.dst[1].sN : a.dst[2].sN);
+            d.sC = seg == 0 ? a.dst[0].sC : (seg == 1 ? a.dst[1].sC : a.dst[2].sC);
+            d.sH = seg == 0 ? a.dst[0].sH : (seg == 1 ? a.dst[1].sH : a.dst[2].sH);
+            d.accumulate = seg == 0 ? a.dst[0].accumulate : (seg == 1 ? a.dst[1].accumulate : a.dst[2].accumulate);
 #pragma unroll
             for (int ni = 0; ni < WN; ++ni) {
                 const int pix = (wn * WN + ni) * 32 + l31;
@@ -243,10 +304,22 @@ static TileChoice pick_tile(const ConvArgs& a, const ConvShape& s) {
         long long tiles = (long long)a.N * ((a.Hout + t.TH - 1) / t.TH) * ((a.Wout + t.TW - 1) / t.TW);
         if (tiles * (a.CoutPad / 64) < 512) t.MT = 32;
     }
+    if (t.MT == 32 && t.TW == 32 && s.stride == 1 && !dilated) {
+        // thin layers (Cout <= 32, the full-resolution ones): a taller pixel tile doubles the MFMA
+        // work per staged chunk and halves the halo overhead
+        long long tiles16 = (long long)a.N * ((a.Hout + 15) / 16) * ((a.Wout + 31) / 32);
+        if (tiles16 * (a.CoutPad / 32) >= 1024) t.TH = 16;
+    }
     return t;
 }
 
+bool ws_pick(const ConvArgs& a, const ConvShape& s, int* MT_out, int* TH_out);
+void ws_fill_tiling(ConvArgs& a, int MT, int TH);
+void ws_launch_conv(const ConvArgs& a, const ConvShape& s, int MT, int TH, hipStream_t st);
+
 void conv_fill_tiling(ConvArgs& a, const ConvShape& s) {
+    int wmt, wth;
+    if (ws_pick(a, s, &wmt, &wth)) { ws_fill_tiling(a, wmt, wth); return; }
     TileChoice t = pick_tile(a, s);
     a.tiles_w = (a.Wout + t.TW - 1) / t.TW;
     a.tiles_h = (a.Hout + t.TH - 1) / t.TH;
@@ -281,6 +354,10 @@ static void launch_by_tile(const ConvArgs& a, const TileChoice& t, hipStream_t s
     if (t.TW == 32) {
         if constexpr (DH == 1 && DW == 1) {
             if (t.MT == 64) launch_inst<KS, S, DH, DW, 64, 8, 32, CK, 1>(a, st);
+            else if (t.TH == 16) {
+                if constexpr (S == 1) launch_inst<KS, S, DH, DW, 32, 16, 32, CK, 1>(a, st);
+                else throw Error(-2, "16x32 tiles are stride-1 only");
+            }
             else            launch_inst<KS, S, DH, DW, 32, 8, 32, CK, 1>(a, st);
         } else {
             throw Error(-2, "dilated conv uses TW=16 tiles only");
@@ -293,6 +370,17 @@ static void launch_by_tile(const ConvArgs& a, const TileChoice& t, hipStream_t s
 
 double launch_conv(const ConvArgs& a_in, const ConvShape& s, hipStream_t st) {
     ConvArgs a = a_in;
+    static const int dbg = getenv("VR_CONV_DBG") ? atoi(getenv("VR_CONV_DBG")) : 0;
+    a.dbg = dbg;
+    {
+        int wmt, wth;
+        if (ws_pick(a, s, &wmt, &wth)) {
+            VR_CHECK(a.nsrc >= 1 && a.nsrc <= 3, -2, "conv takes 1..3 sources");
+            ws_fill_tiling(a, wmt, wth);
+            ws_launch_conv(a, s, wmt, wth, st);
+            return 2.0 * a.N * (double)a.Hout * a.Wout * (double)a.Cout * a.Cin * s.KS * s.KS;
+        }
+    }
     conv_fill_tiling(a, s);
     TileChoice t = pick_tile(a, s);
     VR_CHECK(a.CoutPad % t.MT == 0 && a.CoutPad % 32 == 0, -2, "CoutPad must be a multiple of the cout tile");

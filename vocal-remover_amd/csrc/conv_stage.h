@@ -12,6 +12,25 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float act_apply(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+// Fields of a.src[si] for a wave-uniform si, selected one by one with scalar selects: indexing the
+// by-value kernel argument dynamically makes the compiler keep a copy of it in scratch memory.
+struct SrcSel {
+    const float *p, *aff0, *aff1, *post;
+    long long sN, sC, sH;
+    int C, H, W, hsplit, up, zins;
+    float slope, rh, rw;
+};
+#define VR_SEL_F(a, si, f) ((si) == 0 ? (a).src[0].f : ((si) == 1 ? (a).src[1].f : (a).src[2].f))
+#define VR_SELECT_SRC(s, a, si)                                                                       \
+    do {                                                                                              \
+        (s).p = VR_SEL_F(a, si, p); (s).aff0 = VR_SEL_F(a, si, aff0); (s).aff1 = VR_SEL_F(a, si, aff1); \
+        (s).post = VR_SEL_F(a, si, post); (s).sN = VR_SEL_F(a, si, sN); (s).sC = VR_SEL_F(a, si, sC);   \
+        (s).sH = VR_SEL_F(a, si, sH); (s).C = VR_SEL_F(a, si, C); (s).H = VR_SEL_F(a, si, H);           \
+        (s).W = VR_SEL_F(a, si, W); (s).hsplit = VR_SEL_F(a, si, hsplit); (s).up = VR_SEL_F(a, si, up); \
+        (s).zins = VR_SEL_F(a, si, zins); (s).slope = VR_SEL_F(a, si, slope);                           \
+        (s).rh = VR_SEL_F(a, si, rh); (s).rw = VR_SEL_F(a, si, rw);                                     \
+    } while (0)
+
 // Stage channels [c0, c0+CK) of the virtual input for the tile whose top-left virtual coordinate is
 // (hbase, wbase) into Xs[cl*CS + hh*TWp + ww], hh < TH_in, ww < TW_in.  One channel per wave pass,
 // lanes over the tile; all global loads of a batch are issued before any is consumed (addresses
@@ -102,6 +121,210 @@ __device__ __forceinline__ void stage_input_chunk(const ConvArgs& a, float* Xs, 
                     if (e < NE) dst[hh * TWp + ww] = v;
                 }
             }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Split (issue-early / write-late) staging for the pipelined conv kernel.
+//
+// The staging loop used to be VALU-bound (index arithmetic, clamps, 64-bit addressing and four-tap
+// interpolation set-up per element per channel).  Everything that depends only on the tile geometry
+// is now computed ONCE per workgroup into small LDS tables, indexed by the flat tile element
+// e = lane + 64*pass (the same for every wave, every channel and every chunk):
+//   goff[s][e]  element offset inside a channel plane of plain source s (clamped; zero-inserted
+//               sources already halved)
+//   meta[e]     LDS offset hh*TWp+ww | valid bit per source (16+s) | "row below hsplit" bit (19+s)
+//   lowoff[el]  offset inside a channel plane of the LOW-RES tile element el (upsampled sources)
+//   itp[e]      {q0 = scratch offset of the top-left tap, d = w1p | (h1p*LW) << 8, lambda_h, lambda_w}
+// Per channel the loader then is: table read + global_load(sgpr base, vgpr offset) in the issue
+// phase; fma / max / select / ds_write in the write phase.  Upsampled sources fetch only the
+// low-res tile (<= LH x LW values instead of four taps per output element), transform it once
+// into a wave-private scratch and interpolate from there.
+// All upsampled sources of one conv share H, W and the row stride (checked on the host).
+// ---------------------------------------------------------------------------------------------------
+template <int TH_in, int TW_in>
+struct StageGeom {
+    static constexpr int NE = TH_in * TW_in;
+    static constexpr int NP = (NE + 63) / 64;
+    static constexpr int NEp = NP * 64;
+    static constexpr int NPX = NP + 5;            // prefetch registers per channel: NP raw values + (sc0, sh0, sc1, sh1, post)
+    static constexpr int LH = TH_in / 2 + 2, LW = TW_in / 2 + 2;     // low-res footprint of the haloed tile
+    static constexpr int NL = LH * LW;
+    static constexpr int NPL = (NL + 63) / 64;
+    static constexpr int NLp = NPL * 64;
+    // LDS floats: goff[3][NEp] + meta[NEp] + lowoff[NLp] + itp[NEp][4] + per-wave scratch 4*NL
+    static constexpr int TAB = 3 * NEp + NEp + NLp + 4 * NEp;
+    static constexpr int SCR = 4 * NL;
+    static_assert(NPL <= NP, "low-res tile must fit the prefetch registers");
+};
+
+template <int TH_in, int TW_in, int TWp>
+__device__ __forceinline__ void build_stage_tables(const ConvArgs& a, int* tab, int hbase, int wbase, int tid) {
+    using G = StageGeom<TH_in, TW_in>;
+    int* goff = tab;
+    int* meta = tab + 3 * G::NEp;
+    int* lowoff = meta + G::NEp;
+    int* itp = lowoff + G::NLp;
+    // which source (if any) is upsampled: they all share geometry
+    int us = -1;
+    if (a.src[0].up) us = 0;
+    if (a.nsrc > 1 && a.src[1].up) us = 1;
+    if (a.nsrc > 2 && a.src[2].up) us = 2;
+    float rh = 0.f, rw = 0.f; int UH = 1, UW = 1; long long usH = 0;
+    if (us == 0) { rh = a.src[0].rh; rw = a.src[0].rw; UH = a.src[0].H; UW = a.src[0].W; usH = a.src[0].sH; }
+    if (us == 1) { rh = a.src[1].rh; rw = a.src[1].rw; UH = a.src[1].H; UW = a.src[1].W; usH = a.src[1].sH; }
+    if (us == 2) { rh = a.src[2].rh; rw = a.src[2].rw; UH = a.src[2].H; UW = a.src[2].W; usH = a.src[2].sH; }
+    const int hb = hbase < 0 ? 0 : (hbase >= a.Hin ? a.Hin - 1 : hbase);
+    const int wb = wbase < 0 ? 0 : (wbase >= a.Win ? a.Win - 1 : wbase);
+    const int hl0 = (int)(rh * (float)hb), wl0 = (int)(rw * (float)wb);
+    for (int e = tid; e < G::NEp; e += 256) {
+        const int ec = e < G::NE ? e : G::NE - 1;
+        const int hh = ec / TW_in, ww = ec % TW_in;
+        const int hi = hbase + hh, wi = wbase + ww;
+        const bool inb = hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win;
+        int m = hh * TWp + ww;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            int g = 0;
+            if (s < a.nsrc && !a.src[s].up) {
+                const int zs = a.src[s].zins;
+                int hs = hi >> zs, ws = wi >> zs;
+                bool ok = inb;
+                if (zs) ok = ok && !((hi | wi) & 1) && hs < a.src[s].H && ws < a.src[s].W;
+                hs = hs < 0 ? 0 : (hs >= a.src[s].H ? a.src[s].H - 1 : hs);
+                ws = ws < 0 ? 0 : (ws >= a.src[s].W ? a.src[s].W - 1 : ws);
+                g = (int)(hs * a.src[s].sH) + ws;
+                if (ok) m |= 1 << (16 + s);
+                if (hs < a.src[s].hsplit) m |= 1 << (19 + s);
+            } else if (s < a.nsrc) {
+                if (inb) m |= 1 << (16 + s);
+                m |= 1 << (19 + s);
+            }
+            goff[s * G::NEp + e] = g;
+        }
+        meta[e] = m;
+        // interpolation set-up (torch upsample_bilinear2d, align_corners=True: src = dst*(in-1)/(out-1))
+        const int hc = hi < 0 ? 0 : (hi >= a.Hin ? a.Hin - 1 : hi);
+        const int wc = wi < 0 ? 0 : (wi >= a.Win ? a.Win - 1 : wi);
+        const float h1r = rh * (float)hc, w1r = rw * (float)wc;
+        const int h1 = (int)h1r, w1 = (int)w1r;
+        const int h1p = (h1 < UH - 1) ? 1 : 0, w1p = (w1 < UW - 1) ? 1 : 0;
+        itp[e * 4 + 0] = (h1 - hl0) * G::LW + (w1 - wl0);
+        itp[e * 4 + 1] = w1p | ((h1p * G::LW) << 8);
+        itp[e * 4 + 2] = __float_as_int(h1r - (float)h1);
+        itp[e * 4 + 3] = __float_as_int(w1r - (float)w1);
+    }
+    for (int el = tid; el < G::NLp; el += 256) {
+        const int ec = el < G::NL ? el : G::NL - 1;
+        int hs = hl0 + ec / G::LW, ws = wl0 + ec % G::LW;
+        hs = hs >= UH ? UH - 1 : hs;
+        ws = ws >= UW ? UW - 1 : ws;
+        lowoff[el] = (int)(hs * usH) + ws;
+    }
+}
+
+template <int TH_in, int TW_in, int CK, int NWAVES>
+__device__ __forceinline__ void issue_input_loads(const ConvArgs& a, const int* tab, int c0, int n, int wave, int lane,
+                                                  float (&raw)[(CK + NWAVES - 1) / NWAVES][StageGeom<TH_in, TW_in>::NPX]) {
+    using G = StageGeom<TH_in, TW_in>;
+    constexpr int CPW = (CK + NWAVES - 1) / NWAVES;
+    const int* lowoff = tab + 4 * G::NEp;
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+        const int cl = wave + i * NWAVES;
+        int ci = c0 + cl;
+        ci = (cl < CK && ci < a.Cin) ? ci : a.Cin - 1;           // keep the loads unconditional
+        const int si = (ci >= a.c1) + (ci >= a.c2);
+        const int clc = ci - (si == 0 ? 0 : (si == 1 ? a.c1 : a.c2));
+        const float* p = VR_SEL_F(a, si, p);
+        const long long sN = VR_SEL_F(a, si, sN), sC = VR_SEL_F(a, si, sC);
+        const int up = VR_SEL_F(a, si, up);
+        const float* base = p + (long long)n * sN + (long long)clc * sC;
+        {   // the producer's BatchNorm affine and the dropout keep-mask are prefetched too: fetched in the
+            // write stage they would expose one dependent global-load latency per channel
+            const float* aff0 = VR_SEL_F(a, si, aff0);
+            const float* aff1 = VR_SEL_F(a, si, aff1);
+            const float* postp = VR_SEL_F(a, si, post);
+            const int srcC = VR_SEL_F(a, si, C);
+            float sc0 = 1.f, sh0 = 0.f, sc1 = 1.f, sh1 = 0.f, post = 1.f;
+            if (aff0) { sc0 = aff0[2 * clc]; sh0 = aff0[2 * clc + 1]; }
+            if (aff1) { sc1 = aff1[2 * clc]; sh1 = aff1[2 * clc + 1]; }
+            if (postp) post = postp[n * srcC + clc];
+            raw[i][G::NP + 0] = sc0; raw[i][G::NP + 1] = sh0; raw[i][G::NP + 2] = sc1; raw[i][G::NP + 3] = sh1;
+            raw[i][G::NP + 4] = post;
+        }
+        // ONE store site per register: two branches writing raw[i][j] get merged by the optimizer into
+        // a store through a pointer phi, which pins the whole array in scratch memory.
+        const int* t = up ? (lowoff + lane) : (tab + si * G::NEp + lane);
+#pragma unroll
+        for (int j = 0; j < G::NP; ++j) {
+            int off = t[j * 64];
+            if (j >= G::NPL && up) off = 0;      // beyond the low-res tile: harmless in-bounds dummy load
+            raw[i][j] = base[off];
+        }
+    }
+}
+
+template <int TH_in, int TW_in, int CS, int CK, int NWAVES>
+__device__ __forceinline__ void write_input_stage(const ConvArgs& a, const int* tab, float* Xs, float* scratch /* per-wave [NL] */,
+                                                  int c0, int n, int wave, int lane,
+                                                  const float (&raw)[(CK + NWAVES - 1) / NWAVES][StageGeom<TH_in, TW_in>::NPX]) {
+    using G = StageGeom<TH_in, TW_in>;
+    constexpr int CPW = (CK + NWAVES - 1) / NWAVES;
+    const int* meta = tab + 3 * G::NEp + lane;
+    const int4* itp = reinterpret_cast<const int4*>(tab + 4 * G::NEp + G::NLp) + lane;
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+        const int cl = wave + i * NWAVES;
+        if (cl >= CK) continue;
+        const int ci = c0 + cl;
+        float* dst = Xs + cl * CS;
+        if (ci >= a.Cin) {
+#pragma unroll
+            for (int j = 0; j < G::NP; ++j)
+                if (lane + j * 64 < G::NE) dst[meta[j * 64] & 0xffff] = 0.f;
+            continue;
+        }
+        const int si = (ci >= a.c1) + (ci >= a.c2);
+        const int clc = ci - (si == 0 ? 0 : (si == 1 ? a.c1 : a.c2));
+        const int up = VR_SEL_F(a, si, up);
+        const float slope = VR_SEL_F(a, si, slope);
+        const float sc0 = raw[i][G::NP + 0], sh0 = raw[i][G::NP + 1], sc1 = raw[i][G::NP + 2], sh1 = raw[i][G::NP + 3];
+        const float post = raw[i][G::NP + 4];
+        const int okbit = 1 << (16 + si), lobit = 1 << (19 + si);
+        if (!up) {
+#pragma unroll
+            for (int j = 0; j < G::NP; ++j) {
+                const int m = meta[j * 64];
+                const bool lo = m & lobit;
+                float v = fmaf(raw[i][j], lo ? sc0 : sc1, lo ? sh0 : sh1);
+                v = fmaxf(v, v * slope) * post;                  // slope in [0,1]: = v > 0 ? v : v*slope
+                v = (m & okbit) ? v : 0.f;
+                if (lane + j * 64 < G::NE) dst[m & 0xffff] = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < G::NPL; ++j) {
+                const float t = fmaf(raw[i][j], sc0, sh0);
+                if (lane + j * 64 < G::NL) scratch[lane + j * 64] = fmaxf(t, t * slope);
+            }
+            // the same wave wrote and reads the scratch: one wave's LDS operations complete in order
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < G::NP; ++j) {
+                const int m = meta[j * 64];
+                const int4 u = itp[j * 64];
+                const float* q0 = scratch + u.x;
+                const int d1 = u.y & 0xff, d2 = u.y >> 8;
+                const float h1l = __int_as_float(u.z), w1l = __int_as_float(u.w);
+                const float h0l = 1.f - h1l, w0l = 1.f - w1l;
+                float v = (h0l * (w0l * q0[0] + w1l * q0[d1]) + h1l * (w0l * q0[d2] + w1l * q0[d2 + d1])) * post;
+                v = (m & okbit) ? v : 0.f;
+                if (lane + j * 64 < G::NE) dst[m & 0xffff] = v;
+            }
+            __builtin_amdgcn_wave_barrier();                     // scratch is reused by this wave's next channel
         }
     }
 }

@@ -413,6 +413,15 @@ void Model::build_fwd_args(Conv& L, const std::vector<SrcSpec>& srcs, int N, boo
         ctot += sp.t.C;
     }
     VR_CHECK(ctot == L.Cin, -2, "conv " + L.name + ": channel count mismatch");
+    {   // the loader keeps ONE interpolation table per workgroup: upsampled sources must share geometry
+        const ConvSrc* u = nullptr;
+        for (int i = 0; i < a.nsrc; ++i) {
+            if (!a.src[i].up) continue;
+            if (u) VR_CHECK(u->H == a.src[i].H && u->W == a.src[i].W && u->sH == a.src[i].sH, -2,
+                            "conv " + L.name + ": upsampled sources must share H, W and row stride");
+            u = &a.src[i];
+        }
+    }
     a.c1 = a.nsrc >= 2 ? srcs[0].t.C : L.Cin;
     a.c2 = a.nsrc >= 3 ? srcs[0].t.C + srcs[1].t.C : L.Cin;
     a.Cin = L.Cin;

@@ -95,6 +95,7 @@ struct ConvArgs {
     int N, Hout, Wout, Hin, Win;
     int pad_h, pad_w;
     int tiles_w, tiles_h, npt, nct;
+    int dbg;                   // perf experiments only (VR_CONV_DBG): 1 = skip staging, 2 = skip MFMAs
 };
 
 struct ConvShape {             // static description used by the launcher
