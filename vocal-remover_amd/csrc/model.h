@@ -131,6 +131,8 @@ public:
     void profile_end(double* conv_ms, double* conv_flops, double* other_ms, int* launches);
 
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;          // eval mode: the high-band chain runs here
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
 private:
     // arenas

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace vr {
@@ -125,6 +126,11 @@ Model::Model(int device_, int n_fft_, int hop_, int nout_, int nout_lstm_)
     VR_CHECK((max_bin / 2) % 16 == 0, -2, "n_fft/4 must be a multiple of 16 (four stride-2 encoders)");
     VR_HIP(hipSetDevice(device));
     VR_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    if (!getenv("VR_NO_SIDE_STREAM")) {
+        VR_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+        VR_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        VR_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    }
     const int nin = 2;
     const int nin_lstm = max_bin / 2;
     // lib/nets.py:59-80
@@ -219,6 +225,7 @@ Model::~Model() {
     hipFree(ws.base); hipFree(io.base); hipFree(gs.base);
     hipFree(g_arena); hipFree(m_arena); hipFree(v_arena); hipFree(wt_arena); hipFree(d_flip); hipFree(dropout_buf);
     hipFree(plan.twiddle); hipFree(plan.window);
+    if (side_stream) { hipStreamSynchronize(side_stream); hipStreamDestroy(side_stream); hipEventDestroy(ev_fork); hipEventDestroy(ev_join); }
     if (stream) hipStreamDestroy(stream);
 }
 
@@ -654,17 +661,33 @@ Tensor Model::run_net(const Tensor& x) {
         return v;
     };
     Tensor v;
+    // The low-band chain (stg1_low -> stg2_low) and the high-band chain (stg1_high -> stg2_high) are
+    // independent until stage 3 (lib/nets.py:91-98).  In eval mode they run on two HIP streams so the
+    // small 1/16-resolution layers of one chain fill the CUs the other leaves idle.
+    // (not while per-kernel HIP-event timing is on: overlapping kernels would inflate each other's time)
+    const bool fork = !dry && !training && !profiling && side_stream != nullptr;
+    hipStream_t main_stream = stream;
+    if (fork) {
+        VR_HIP(hipEventRecord(ev_fork, main_stream));
+        VR_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
+    }
     Tensor l1r = run_basenet(nets_[0], {SrcSpec{xl}}, B, nullptr);
     v = half(aux1, 0);
     Tensor l1 = run_conv(tail1, {SrcSpec{l1r}}, B, &v, nullptr, false);
-    v = half(aux1, 1);
-    Tensor h1 = run_basenet(nets_[1], {SrcSpec{xh}}, B, &v);
-    tap("l1", l1); tap("h1", h1);
     Tensor l2r = run_basenet(nets_[2], {SrcSpec{xl}, SrcSpec{l1}}, B, nullptr);
     v = half(aux2, 0);
     Tensor l2 = run_conv(tail2, {SrcSpec{l2r}}, B, &v, nullptr, false);
+    if (fork) stream = side_stream;
+    v = half(aux1, 1);
+    Tensor h1 = run_basenet(nets_[1], {SrcSpec{xh}}, B, &v);
     v = half(aux2, 1);
     Tensor h2 = run_basenet(nets_[3], {SrcSpec{xh}, SrcSpec{h1}}, B, &v);
+    if (fork) {
+        VR_HIP(hipEventRecord(ev_join, side_stream));
+        stream = main_stream;
+        VR_HIP(hipStreamWaitEvent(main_stream, ev_join, 0));
+    }
+    tap("l1", l1); tap("h1", h1);
     tap("l2", l2); tap("h2", h2);
     aux1.aff0 = l1.aff0; aux1.aff1 = h1.aff0; aux1.hsplit = bandw;
     aux2.aff0 = l2.aff0; aux2.aff1 = h2.aff0; aux2.hsplit = bandw;
