@@ -34,7 +34,8 @@ enum vr_status {
     VR_ERR_HIP = -3,            /* a HIP runtime call failed                                       */
     VR_ERR_OOM = -4,            /* workspace planning / allocation failure                         */
     VR_ERR_CROP_CENTER = -5,    /* reference ValueError of spec_utils.crop_center (spec_utils.py:15) */
-    VR_ERR_EMPTY_MASK = -6      /* reference `assert mask.size()[3] > 0` (nets.py:129,139)         */
+    VR_ERR_EMPTY_MASK = -6,     /* reference `assert mask.size()[3] > 0` (nets.py:129,139)         */
+    VR_ERR_INDEX = -7           /* reference IndexError in merge_artifacts (spec_utils.py:65, empty idx) */
 };
 
 const char* vr_last_error(void);
@@ -72,7 +73,8 @@ int vr_istft(vr_handle h, const float* spec, int spec_on_device, int T, float* w
 
 /* Separator(model, device, batchsize, cropsize).separate / separate_tta     inference.py:70-102
  * spec [2,bins,T] complex64 -> y_spec (instruments), v_spec (vocals), same shape.
- * batchsize <= 0: all crops of a pass in one device batch.                                        */
+ * `tta` is a flag word: bit 0 = --tta (separate_tta), bit 1 = --postprocess (spec_utils.merge_artifacts,
+ * lib/spec_utils.py:60-93, inference.py:27-30).  batchsize <= 0: all crops of a pass in one device batch. */
 int vr_separate(vr_handle h, const float* spec, int spec_on_device, int T, int tta, int batchsize,
                 int cropsize, float* y_spec, float* v_spec, int out_on_device);
 
@@ -120,6 +122,10 @@ int vr_debug_conv2d(vr_handle h, const float* x, int N, int Cin, int H, int W, c
 int vr_debug_conv2d_backward(vr_handle h, const float* x, int N, int Cin, int H, int W, const float* w, int Cout,
                              int ksize, int stride, int dil_h, int dil_w, int upsample, const float* affine,
                              float slope, const float* dz, float* dx_out, float* dw_out);
+/* Host half of --postprocess (no GPU involved): per-frame mask minimum [T] -> merge_artifacts blend
+ * weight [T] (lib/spec_utils.py:64-87), incl. the reference's IndexError / ValueError cases.        */
+int vr_debug_merge_artifacts_weight(const float* frame_min, int T, float thres, int min_range, int fade_size,
+                                    float* weight_out);
 /* Record intermediate activations of the next vr_forward and read them back (post-activation). */
 int vr_debug_record_taps(vr_handle h, int enable);
 int64_t vr_debug_get_tap(vr_handle h, const char* name, float* host, int64_t capacity_floats, int64_t* shape4);

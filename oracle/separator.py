@@ -42,6 +42,43 @@ def postprocess(X_spec, mask):
     return y_spec, v_spec
 
 
+def merge_artifacts(y_mask, thres=0.05, min_range=64, fade_size=32):
+    """spec_utils.merge_artifacts, lib/spec_utils.py:60-93 (--postprocess), restated.
+
+    Frames whose mask minimum over (channel, bin) stays above `thres` for more than `min_range`
+    consecutive frames are blended towards 1 (y += w * (1 - y)) with linear fades of `fade_size`.
+    numpy slice semantics (negative starts, broadcast errors) and the IndexError on an empty
+    above-threshold set are the reference's own behaviour and are kept.
+    """
+    if min_range < fade_size * 2:
+        raise ValueError('min_range must be >= fade_size * 2')
+    T = y_mask.shape[2]
+    above = np.flatnonzero(y_mask.min(axis=(0, 1)) > thres)
+    first = above[0]                                   # IndexError when nothing is above the threshold
+    breaks = np.flatnonzero(np.diff(above) != 1)
+    starts = np.concatenate([[first], above[breaks + 1]])
+    ends = np.concatenate([above[breaks], [above[-1]]])
+    w = np.zeros(T, dtype=y_mask.dtype)
+    prev_end = None
+    for s, e in zip(starts, ends):
+        if not (e - s > min_range):
+            continue
+        s, e = int(s), int(e)
+        if prev_end is not None and s - prev_end < fade_size:
+            s = prev_end - fade_size * 2
+        if s != 0:
+            w[s:s + fade_size] = np.linspace(0, 1, fade_size)
+        else:
+            s -= fade_size
+        if e != T:
+            w[e - fade_size:e] = np.linspace(1, 0, fade_size)
+        else:
+            e += fade_size
+        w[s + fade_size:e - fade_size] = 1
+        prev_end = e
+    return y_mask + w[None, None, :] * (1 - y_mask)
+
+
 def separate_mask(X_spec, sd, n_fft=2048, batchsize=4, cropsize=256, offset=64):
     """Mask half of Separator.separate, inference.py:70-77."""
     n_frame = X_spec.shape[2]
@@ -72,9 +109,12 @@ def separate_tta_mask(X_spec, sd, n_fft=2048, batchsize=4, cropsize=256, offset=
     return (mask[:, :, :n_frame] + mask_tta[:, :, :n_frame]) * 0.5
 
 
-def separate(X_spec, sd, tta=False, **kw):
-    """Separator.separate / separate_tta -> (y_spec, v_spec), inference.py:70-102."""
+def separate(X_spec, sd, tta=False, post=False, **kw):
+    """Separator.separate / separate_tta -> (y_spec, v_spec), inference.py:70-102
+    (post=True: Separator(postprocess=True), inference.py:27-30)."""
     mask = (separate_tta_mask if tta else separate_mask)(X_spec, sd, **kw)
+    if post:
+        mask = merge_artifacts(np.abs(mask))
     return postprocess(X_spec, mask)
 
 

@@ -101,3 +101,62 @@ def test_dropin_shadow_modules_resolve(built):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.CascadedNet is built.nets.CascadedNet
+
+
+def _ref_merge(reference_lib):
+    import importlib
+    return importlib.import_module('lib.spec_utils').merge_artifacts
+
+
+def _mask_from_frame_min(fmin):
+    m = np.full((2, 5, len(fmin)), 0.9, np.float32)
+    m[1, 3] = fmin
+    return m
+
+
+MERGE_CASES = {
+    'one_long_run': lambda T: np.where((np.arange(T) > 40) & (np.arange(T) < 300), 0.5, 0.01),
+    'starts_at_zero': lambda T: np.where(np.arange(T) < 200, 0.4, 0.0),
+    'two_runs_close': lambda T: np.where(((np.arange(T) > 10) & (np.arange(T) < 120)) | ((np.arange(T) > 130) & (np.arange(T) < 330)), 0.3, 0.02),
+    'short_runs_only': lambda T: np.where((np.arange(T) % 50) < 30, 0.6, 0.01),
+    'runs_to_the_end': lambda T: np.where(np.arange(T) > 250, 0.2, 0.04),
+    'all_above': lambda T: np.full(T, 0.5),
+}
+
+
+@pytest.mark.parametrize('name', sorted(MERGE_CASES))
+def test_merge_artifacts_host_logic_matches_reference(built, reference_lib, name):
+    """--postprocess: the library's host half and the oracle restatement vs lib/spec_utils.merge_artifacts."""
+    ref = _ref_merge(reference_lib)
+    T = 400
+    fmin = MERGE_CASES[name](T).astype(np.float32)
+    mask = _mask_from_frame_min(fmin)
+    want = ref(mask.copy())
+    got_oracle = separator.merge_artifacts(mask.copy())
+    assert np.abs(got_oracle - want).max() < 1e-7
+    w = np.empty(T, np.float32)
+    L = built.native.lib()
+    frame_min = np.ascontiguousarray(mask.min(axis=(0, 1)))      # keep alive: np_ptr does not hold a reference
+    built.native.check(L.vr_debug_merge_artifacts_weight(built.native.np_ptr(frame_min), T, 0.05, 64, 32,
+                                                         built.native.np_ptr(w)))
+    got = mask + w[None, None, :] * (1 - mask)
+    assert np.abs(got - want).max() < 1e-6
+
+
+def test_merge_artifacts_error_behaviour(built, reference_lib):
+    ref = _ref_merge(reference_lib)
+    T = 300
+    mask = _mask_from_frame_min(np.zeros(T, np.float32))
+    with pytest.raises(IndexError):
+        ref(mask.copy())
+    with pytest.raises(IndexError):
+        separator.merge_artifacts(mask.copy())
+    w = np.empty(T, np.float32)
+    L = built.native.lib()
+    zeros_f, ones_f = np.zeros(T, np.float32), np.ones(T, np.float32)
+    with pytest.raises(IndexError):
+        built.native.check(L.vr_debug_merge_artifacts_weight(built.native.np_ptr(zeros_f), T, 0.05, 64, 32,
+                                                             built.native.np_ptr(w)))
+    with pytest.raises(ValueError):      # min_range < 2 * fade_size (lib/spec_utils.py:61-62)
+        built.native.check(L.vr_debug_merge_artifacts_weight(built.native.np_ptr(ones_f), T, 0.05, 32, 32,
+                                                             built.native.np_ptr(w)))

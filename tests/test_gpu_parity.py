@@ -260,3 +260,24 @@ def test_separate_wave_pipeline(vr, small):
     spec_o = stft_np.wave_to_spectrogram(wave, hop, n_fft)
     yo, vo = separator.separate(spec_o, sd, n_fft=n_fft, batchsize=4, cropsize=160)
     assert np.abs(y - stft_np.spectrogram_to_wave(yo.astype(np.complex64), hop)).max() < 1e-4
+
+
+@pytest.mark.parametrize('tta', [False, True])
+def test_separator_postprocess_merge_artifacts(vr, small, tta):
+    """Separator(postprocess=True): inference.py:27-30 + spec_utils.merge_artifacts, on device."""
+    model, sd, n_fft = small
+    sd2 = weights.clone_state_dict(sd)
+    sd2['out.weight'] = sd['out.weight'] * 0.05          # keeps every frame's mask minimum above the 0.05 threshold
+    model.load_state_dict(sd2)
+    rng = np.random.default_rng(8)
+    T = 300
+    X = (rng.standard_normal((2, n_fft // 2 + 1, T)) + 1j * rng.standard_normal((2, n_fft // 2 + 1, T))).astype(np.complex64)
+    want_y, want_v = separator.separate(X.copy(), sd2, tta=tta, post=True, n_fft=n_fft, batchsize=2, cropsize=160)
+    plain_y, _ = separator.separate(X.copy(), sd2, tta=tta, post=False, n_fft=n_fft, batchsize=2, cropsize=160)
+    assert np.abs(want_y - plain_y).max() > 0.05 * np.abs(X).max()          # the flag really changes the result
+    sp = vr.inference.Separator(model, torch.device('cuda:0'), batchsize=0, cropsize=160, postprocess=True)
+    got_y, got_v = (sp.separate_tta if tta else sp.separate)(X.copy())
+    scale = np.abs(X).max()
+    assert np.abs(got_y - want_y).max() < 1e-4 * scale
+    assert np.abs(got_v - want_v).max() < 1e-4 * scale
+    model.load_state_dict(sd)

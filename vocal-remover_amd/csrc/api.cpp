@@ -218,6 +218,16 @@ int vr_debug_conv2d_backward(vr_handle h, const float* x, int N, int Cin, int H,
     });
 }
 
+int vr_debug_merge_artifacts_weight(const float* frame_min, int T, float thres, int min_range, int fade_size,
+                                    float* weight_out) {
+    return guard([&] {
+        VR_CHECK(frame_min && weight_out && T > 0, VR_ERR_BAD_ARGUMENT, "null argument");
+        std::vector<float> f(frame_min, frame_min + T), w;
+        vr::merge_artifacts_weight(f, w, thres, min_range, fade_size);
+        std::memcpy(weight_out, w.data(), (size_t)T * sizeof(float));
+    });
+}
+
 int vr_debug_record_taps(vr_handle h, int enable) {
     NEED(h);
     return guard([&] { h->m.record_taps = enable != 0; if (!enable) h->m.taps.clear(); });

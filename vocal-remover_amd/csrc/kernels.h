@@ -112,7 +112,11 @@ void launch_stats_init(unsigned* stats, hipStream_t st);
 // aff[0..3] = (1/coef, 0, 1/coef, 0), coef = max|X| (mode 0) or |lexicographic max| (mode 1)
 void launch_coef_affine(const unsigned* stats, int mode, float* aff, hipStream_t st);
 // y = m*X, v = (1-m)*X with m = mask_a[.., t] (tta=0) or 0.5*(mask_a[.., t] + mask_b[.., t + shift])
+// wgt [T] (or null): per-frame merge_artifacts weight, m += wgt[t] * (1 - m)
 void launch_apply_mask(const float2* spec, int bins, int T, const float* mask_a, int Wa,
-                       const float* mask_b, int Wb, int shift, float2* y, float2* v, hipStream_t st);
+                       const float* mask_b, int Wb, int shift, const float* wgt, float2* y, float2* v, hipStream_t st);
+// fmin[t] = min over (channel, bin) of the final mask at frame t
+void launch_frame_min(int bins, int T, const float* mask_a, int Wa, const float* mask_b, int Wb, int shift, float* fmin,
+                      hipStream_t st);
 
 }  // namespace vr

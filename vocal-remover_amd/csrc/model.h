@@ -84,6 +84,10 @@ struct BaseNetL {
     LSTMMod lstm;
 };
 
+// host half of spec_utils.merge_artifacts (lib/spec_utils.py:60-93): per-frame mask minimum -> blend weight
+void merge_artifacts_weight(const std::vector<float>& fmin, std::vector<float>& weight, float thres, int min_range,
+                            int fade);
+
 struct ProfileEntry { hipEvent_t e0, e1; double flops; int kind; };
 
 class Model {

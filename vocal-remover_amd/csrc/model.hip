@@ -800,6 +800,47 @@ void Model::istft_api(const float* spec, bool on_dev, int T, float* wave, bool w
     VR_HIP(hipStreamSynchronize(stream));
 }
 
+// spec_utils.merge_artifacts (lib/spec_utils.py:60-93) reduced to its per-frame weight vector
+// (the reference builds a [2, bins, T] weight that is constant over channel and bin).  numpy slice
+// semantics are kept: negative starts wrap, a slice/linspace length mismatch is numpy's ValueError,
+// an empty above-threshold set is the IndexError the reference raises at `idx[0]`.
+void merge_artifacts_weight(const std::vector<float>& fmin, std::vector<float>& weight, float thres, int min_range,
+                            int fade) {
+    const int T = (int)fmin.size();
+    VR_CHECK(min_range >= fade * 2, -2, "min_range must be >= fade_size * 2");
+    weight.assign((size_t)T, 0.f);
+    std::vector<int> idx;
+    for (int t = 0; t < T; ++t) if (fmin[t] > thres) idx.push_back(t);
+    VR_CHECK(!idx.empty(), -7, "index 0 is out of bounds for axis 0 with size 0");
+    std::vector<int> starts{idx[0]}, ends;
+    for (size_t i = 1; i < idx.size(); ++i)
+        if (idx[i] - idx[i - 1] != 1) { ends.push_back(idx[i - 1]); starts.push_back(idx[i]); }
+    ends.push_back(idx.back());
+    auto norm = [T](int i) { if (i < 0) i += T; return i < 0 ? 0 : (i > T ? T : i); };
+    auto assign_ramp = [&](int a, int b, bool up) {       // weight[a:b] = linspace(0,1,fade) or linspace(1,0,fade)
+        const int lo = norm(a), hi = norm(b);
+        const int n = hi > lo ? hi - lo : 0;
+        VR_CHECK(n == fade, -2, "could not broadcast input array from shape (" + std::to_string(fade) + ",) into shape (" + std::to_string(n) + ",)");
+        for (int i = 0; i < fade; ++i) {
+            const double x = (double)i / (fade - 1);
+            weight[lo + i] = (float)(up ? x : 1.0 - x);
+        }
+    };
+    bool have_old = false;
+    int old_e = 0;
+    for (size_t k = 0; k < starts.size(); ++k) {
+        int s0 = starts[k], e0 = ends[k];
+        if (!(e0 - s0 > min_range)) continue;
+        if (have_old && s0 - old_e < fade) s0 = old_e - fade * 2;
+        if (s0 != 0) assign_ramp(s0, s0 + fade, true); else s0 -= fade;
+        if (e0 != T) assign_ramp(e0 - fade, e0, false); else e0 += fade;
+        const int lo = norm(s0 + fade), hi = norm(e0 - fade);
+        for (int i = lo; i < hi; ++i) weight[i] = 1.f;
+        old_e = e0;
+        have_old = true;
+    }
+}
+
 // dataset.make_padding (lib/dataset.py:198-205)
 static void make_padding(int width, int cropsize, int offset, int& left, int& right, int& roi) {
     left = offset;
@@ -814,12 +855,14 @@ static size_t separate_scratch_floats(int bins, int T, int cropsize, int offset,
     int l, r, roi;
     make_padding(T, cropsize, offset, l, r, roi);
     const size_t Wpad2 = (size_t)T + l + r + roi;
-    return 2 * (size_t)2 * bins * Wpad2 * (tta ? 2 : 1) + 4096;
+    return 2 * (size_t)2 * bins * Wpad2 * (tta ? 2 : 1) + 2 * (size_t)T + 4096;
 }
 
 void Model::separate_api(const float* spec, bool on_dev, int T, int tta, int batchsize, int cropsize, float* y_spec,
                          float* v_spec, bool out_on_dev) {
     VR_HIP(hipSetDevice(device));
+    const bool post = (tta & 2) != 0;       // flags: bit 0 = --tta, bit 1 = --postprocess
+    tta &= 1;
     VR_CHECK(T > 0, -2, "empty spectrogram");
     VR_CHECK(!training, -2, "separate() runs in eval mode (inference.py:52); call vr_set_mode(h, 0) first");
     check_T(cropsize, offset, 1);
@@ -880,8 +923,24 @@ void Model::separate_api(const float* spec, bool on_dev, int T, int tta, int bat
             launch_head_sigmoid(f3, out_w->dev, d, stream);
         }
     }
+    const float* wgt = nullptr;
+    if (post) {
+        // spec_utils.merge_artifacts (lib/spec_utils.py:60-93): frames whose mask minimum exceeds the
+        // threshold for more than min_range frames are pulled towards 1 with linear fades.  The per-frame
+        // minimum is reduced on the GPU, the O(T) run logic runs on the host, the blend in apply_mask.
+        float* fmin_d = io.allocf((size_t)T);
+        float* wgt_d = io.allocf((size_t)T);
+        launch_frame_min(bins, T, mask[0], Wm[0], tta ? mask[1] : nullptr, Wm[1], roi / 2, fmin_d, stream);
+        std::vector<float> fmin((size_t)T), w;
+        VR_HIP(hipMemcpyAsync(fmin.data(), fmin_d, (size_t)T * sizeof(float), hipMemcpyDeviceToHost, stream));
+        VR_HIP(hipStreamSynchronize(stream));
+        merge_artifacts_weight(fmin, w, 0.05f, 64, 32);
+        VR_HIP(hipMemcpyAsync(wgt_d, w.data(), (size_t)T * sizeof(float), hipMemcpyHostToDevice, stream));
+        VR_HIP(hipStreamSynchronize(stream));
+        wgt = wgt_d;
+    }
     launch_apply_mask(reinterpret_cast<const float2*>(sd), bins, T, mask[0], Wm[0], tta ? mask[1] : nullptr, Wm[1], roi / 2,
-                      reinterpret_cast<float2*>(yd), reinterpret_cast<float2*>(vd), stream);
+                      wgt, reinterpret_cast<float2*>(yd), reinterpret_cast<float2*>(vd), stream);
     if (!out_on_dev) {
         VR_HIP(hipMemcpyAsync(y_spec, yd, spec_f * sizeof(float), hipMemcpyDeviceToHost, stream));
         VR_HIP(hipMemcpyAsync(v_spec, vd, spec_f * sizeof(float), hipMemcpyDeviceToHost, stream));

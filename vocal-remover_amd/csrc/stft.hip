@@ -200,9 +200,36 @@ void launch_coef_affine(const unsigned* stats, int mode, float* aff, hipStream_t
     VR_HIP(hipGetLastError());
 }
 
+// per-frame minimum of the final mask over (channel, bin): input of spec_utils.merge_artifacts
+// (lib/spec_utils.py:64).  One workgroup per 64 frames; lanes along time (coalesced rows).
+__global__ __launch_bounds__(256) void frame_min_kernel(int rows, int T, const float* __restrict__ ma, int Wa,
+                                                        const float* __restrict__ mb, int Wb, int shift,
+                                                        float* __restrict__ fmin) {
+    __shared__ float red[4][64];
+    const int t = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;
+    float m = 3.4e38f;
+    if (t < T) {
+        for (int r = part; r < rows; r += 4) {
+            float v = ma[(long long)r * Wa + t];
+            if (mb) v = (v + mb[(long long)r * Wb + t + shift]) * 0.5f;
+            m = fminf(m, v);
+        }
+    }
+    red[part][threadIdx.x & 63] = m;
+    __syncthreads();
+    if (part == 0 && t < T) fmin[t] = fminf(fminf(red[0][threadIdx.x], red[1][threadIdx.x]), fminf(red[2][threadIdx.x], red[3][threadIdx.x]));
+}
+
+void launch_frame_min(int bins, int T, const float* mask_a, int Wa, const float* mask_b, int Wb, int shift, float* fmin,
+                      hipStream_t st) {
+    hipLaunchKernelGGL(frame_min_kernel, dim3((T + 63) / 64), dim3(256), 0, st, 2 * bins, T, mask_a, Wa, mask_b, Wb, shift, fmin);
+    VR_HIP(hipGetLastError());
+}
+
 __global__ void apply_mask_kernel(const float2* __restrict__ spec, int bins, int T, const float* __restrict__ ma,
-                                  int Wa, const float* __restrict__ mb, int Wb, int shift, float2* __restrict__ y,
-                                  float2* __restrict__ v) {
+                                  int Wa, const float* __restrict__ mb, int Wb, int shift, const float* __restrict__ wgt,
+                                  float2* __restrict__ y, float2* __restrict__ v) {
     const long long total = 2LL * bins * T;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
@@ -210,6 +237,7 @@ __global__ void apply_mask_kernel(const float2* __restrict__ spec, int bins, int
     const long long row = gid / T;
     float m = ma[row * Wa + t];
     if (mb) m = (m + mb[row * Wb + t + shift]) * 0.5f;
+    if (wgt) m += wgt[t] * (1.f - m);            // merge_artifacts: y_mask += weight * (1 - y_mask)
     const float2 z = spec[gid];
     y[gid] = make_float2(m * z.x, m * z.y);
     const float im = 1.f - m;
@@ -217,10 +245,10 @@ __global__ void apply_mask_kernel(const float2* __restrict__ spec, int bins, int
 }
 
 void launch_apply_mask(const float2* spec, int bins, int T, const float* mask_a, int Wa, const float* mask_b, int Wb,
-                       int shift, float2* y, float2* v, hipStream_t st) {
+                       int shift, const float* wgt, float2* y, float2* v, hipStream_t st) {
     const long long total = 2LL * bins * T;
     hipLaunchKernelGGL(apply_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, spec, bins, T, mask_a,
-                       Wa, mask_b, Wb, shift, y, v);
+                       Wa, mask_b, Wb, shift, wgt, y, v);
     VR_HIP(hipGetLastError());
 }
 

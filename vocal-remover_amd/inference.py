@@ -13,10 +13,10 @@ class Separator(object):
         self.device = device
         self.batchsize = batchsize
         self.cropsize = cropsize
-        self.postprocess = postprocess
-        if postprocess:
-            raise NotImplementedError('--postprocess (spec_utils.merge_artifacts, lib/spec_utils.py:60-93) is '
-                                      'outside the hot path built so far (SURVEY.md section 8f, rank 1)')
+        self.postprocess = postprocess      # spec_utils.merge_artifacts (lib/spec_utils.py:60-93), on device
+
+    def _flags(self, tta):
+        return (1 if tta else 0) | (2 if self.postprocess else 0)
 
     def _run(self, X_spec, tta):
         h = self.model._need_handle()
@@ -26,7 +26,7 @@ class Separator(object):
         self.model.eval()                        # inference.py:52
         y_spec = np.empty_like(X_spec)
         v_spec = np.empty_like(X_spec)
-        native.check(native.lib().vr_separate(h.h, native.np_ptr(X_spec), 0, X_spec.shape[2], int(tta),
+        native.check(native.lib().vr_separate(h.h, native.np_ptr(X_spec), 0, X_spec.shape[2], self._flags(tta),
                                               int(self.batchsize), int(self.cropsize),
                                               native.np_ptr(y_spec), native.np_ptr(v_spec), 0))
         return y_spec, v_spec
@@ -59,7 +59,7 @@ class Separator(object):
             y = torch.empty((2, out_len), dtype=torch.float32, device=wave.device)
             v = torch.empty_like(y)
             torch.cuda.current_stream(wave.device).synchronize()
-            native.check(native.lib().vr_separate_wave(h.h, wave.data_ptr(), 1, L, int(tta), int(self.batchsize),
+            native.check(native.lib().vr_separate_wave(h.h, wave.data_ptr(), 1, L, self._flags(tta), int(self.batchsize),
                                                        int(self.cropsize), y.data_ptr(), v.data_ptr(), 1))
             return y, v
         wave = np.ascontiguousarray(np.asarray(wave, dtype=np.float32))
@@ -67,6 +67,6 @@ class Separator(object):
         out_len = hop * (L // hop)
         y = np.empty((2, out_len), dtype=np.float32)
         v = np.empty_like(y)
-        native.check(native.lib().vr_separate_wave(h.h, native.np_ptr(wave), 0, L, int(tta), int(self.batchsize),
+        native.check(native.lib().vr_separate_wave(h.h, native.np_ptr(wave), 0, L, self._flags(tta), int(self.batchsize),
                                                    int(self.cropsize), native.np_ptr(y), native.np_ptr(v), 0))
         return y, v

@@ -44,6 +44,8 @@ _SIGNATURES = {
                         + [c_f32p, ctypes.c_float, c_f32p, c_f32p, c_f32p]),
     'vr_debug_conv2d_backward': (ctypes.c_int, [ctypes.c_void_p, c_f32p] + [ctypes.c_int] * 4 + [c_f32p]
                                  + [ctypes.c_int] * 6 + [c_f32p, ctypes.c_float, c_f32p, c_f32p, c_f32p]),
+    'vr_debug_merge_artifacts_weight': (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int,
+                                                       c_f32p]),
     'vr_debug_record_taps': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'vr_debug_get_tap': (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p, c_f32p, ctypes.c_int64, c_i64p]),
 }
@@ -84,6 +86,8 @@ def check(rc):
         raise ValueError(msg)              # spec_utils.crop_center ValueError (lib/spec_utils.py:15)
     if rc == -6:
         raise AssertionError(msg)          # assert mask.size()[3] > 0 (lib/nets.py:129,139)
+    if rc == -7:
+        raise IndexError(msg)              # merge_artifacts on a mask with no frame above the threshold
     if rc == -2:
         raise ValueError(msg)
     raise VRError('libvr_mi355 error %d: %s' % (rc, msg))
