@@ -9,7 +9,7 @@ def load(path, counter):
     out = {}
     for name, val in db.execute("select name, counter_value from pmc_events where counter_name=? order by start", (counter,)):
         name = re.sub(r'^void ', '', name)
-        name = 'conv_mfma_kernel<*>' if 'conv_mfma_kernel' in name else re.sub(r'\(.*$', '', name)[:60]
+        name = 'conv family (conv_ws + conv_mfma)' if ('conv_mfma_kernel' in name or 'conv_ws_kernel' in name) else re.sub(r'\(.*$', '', name)[:60]
         n, s = out.get(name, (0, 0.0))
         out[name] = (n + 1, s + val)
     return out

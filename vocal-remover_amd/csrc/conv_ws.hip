@@ -134,6 +134,8 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_ws_kernel(const ConvArgs 
     }
 
     // =============================== consumers ===============================================================
+    // static priority: the MFMA waves win issue arbitration over the producer waves sharing their SIMD
+    if (a.dbg != 4) __builtin_amdgcn_s_setprio(2);
     const int khalf = lane >> 5, l31 = lane & 31;
     int boff[WN];
 #pragma unroll
