@@ -1,0 +1,91 @@
+// Microbenchmark: do MFMA waves and VALU / LDS / global-load waves of the same workgroup overlap
+// on gfx950?  Block = 4 MFMA waves (one per SIMD) + 8 worker waves.
+//   hipcc --offload-arch=gfx950 -O3 tools/mfma_overlap.hip -o tools/mfma_overlap.bin
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// kind: 0 VALU fma chains, 1 LDS writes, 2 global loads (L2-resident), 3 LDS reads
+__global__ __launch_bounds__(768) void overlap(const float* __restrict__ in, float* __restrict__ out, int mfma_iters,
+                                               int work_iters, int kind) {
+    __shared__ float lds[16384];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    float s = 0.f;
+    if (wave < 4) {
+        f32x16 acc[4];
+        for (int i = 0; i < 4; ++i)
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        float a = in[tid], b = in[256 + tid];
+        for (int it = 0; it < mfma_iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+            a = -a;
+        }
+        for (int i = 0; i < 4; ++i)
+            for (int r = 0; r < 16; ++r) s += acc[i][r];
+    } else if (kind == 0) {
+        float x0 = in[tid], x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3;
+        const float m = in[tid & 255] * 1e-3f;
+        for (int it = 0; it < work_iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                x0 = fmaf(x0, m, 1.f); x1 = fmaf(x1, m, 1.f); x2 = fmaf(x2, m, 1.f); x3 = fmaf(x3, m, 1.f);
+            }
+        }
+        s = x0 + x1 + x2 + x3;
+    } else if (kind == 1) {
+        for (int it = 0; it < work_iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) lds[(tid - 256 + u * 512 + it) & 16383] = (float)it;
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        s = lds[tid];
+    } else if (kind == 2) {
+        const float* p = in + (tid - 256);
+        for (int it = 0; it < work_iters; ++it) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[((it * 8 + u) * 512 + blockIdx.x * 4096) & ((1 << 22) - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+    } else {
+        for (int it = 0; it < work_iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += lds[(tid - 256 + u * 512 + it) & 16383];
+        }
+    }
+    out[blockIdx.x * 768 + tid] = s;
+}
+
+int main() {
+    const int blocks = 256 * 4;
+    float *in, *out;
+    (void)hipMalloc(&in, (1 << 22) * 4 + 4096);
+    (void)hipMalloc(&out, blocks * 768 * 4);
+    float* h = (float*)malloc((1 << 22) * 4);
+    for (int i = 0; i < (1 << 22); ++i) h[i] = (float)rand() / (float)RAND_MAX - 0.5f;
+    (void)hipMemcpy(in, h, (1 << 22) * 4, hipMemcpyHostToDevice);
+    const char* names[4] = {"VALU fma", "LDS write", "global load", "LDS read"};
+    const int witers[4] = {40000, 20000, 3000, 20000};
+    for (int kind = 0; kind < 4; ++kind) {
+        float t[3];
+        for (int cfg = 0; cfg < 3; ++cfg) {
+            const int mi = cfg == 1 ? 0 : 10000, wi = cfg == 0 ? 0 : witers[kind];
+            hipEvent_t e0, e1;
+            (void)hipEventCreate(&e0);
+            (void)hipEventCreate(&e1);
+            for (int rep = 0; rep < 2; ++rep) {
+                (void)hipEventRecord(e0);
+                hipLaunchKernelGGL(overlap, dim3(blocks), dim3(768), 0, 0, in, out, mi, wi, kind);
+                (void)hipEventRecord(e1);
+                (void)hipEventSynchronize(e1);
+                (void)hipEventElapsedTime(&t[cfg], e0, e1);
+            }
+        }
+        printf("%-12s mfma-only %.2f ms | work-only %.2f ms | both %.2f ms (sum %.2f, max %.2f)\n", names[kind], t[0], t[1],
+               t[2], t[0] + t[1], t[0] > t[1] ? t[0] : t[1]);
+    }
+    return 0;
+}

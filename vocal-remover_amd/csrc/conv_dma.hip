@@ -1,0 +1,389 @@
+// LDS-DMA convolution: the forward conv of lib/layers.py:12-20 (3x3 stride 1/2 and 1x1) for inputs
+// that are PLAIN tensors (no pending BatchNorm affine / activation / dropout / upsample), which is
+// every conv of the eval-mode network once the producer applies BatchNorm+activation in its epilogue.
+//
+// Why a third conv kernel: on gfx950 the fp32 MFMA and the VALU of a SIMD do not overlap
+// (tools/mfma_overlap.hip: MFMA-only 5.0 ms + VALU-only 10.7 ms = 14.7 ms together), so every VALU
+// instruction of a loader is paid in full no matter which wave runs it.  A plain input needs no
+// arithmetic at all: `buffer_load_dwordx4 ... lds` moves 16 B per lane straight from HBM/L2 into
+// LDS (lane-linear destination, per-lane source offset, out-of-range lanes land as zeros = the
+// conv's zero padding), issued by the four MFMA waves themselves -- ~4 instructions per wave per
+// input-channel chunk, no producer waves, no staging registers, no ds_write.
+//
+// LDS image per chunk:  Xs[CK][TH_in][TWq]  (row = image columns [w0*S-pad-XS0, ...) so that every
+// 4-float piece is 16-B aligned in the image row; a piece is either fully inside the row or fully
+// padding because Win % 4 == 0), Ws[tap][CK][MT] (a contiguous re-tiling of w[ci][tap][co0..]).
+// Double-buffered, ONE raw s_barrier per chunk; the DMA of chunk k+1 is in flight while chunk k is
+// multiplied.  The DMA is inline asm on purpose: the compiler would wait vmcnt(0) before the first
+// LDS read that follows a DMA it knows about (cdna_hip_programming.md "Pipelining across barriers").
+#include <cstdlib>
+
+#include "conv_stage.h"
+
+namespace vr {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+template <int KS, int S, int MT, int TH, int TW, int CK>
+struct DmaCfg {
+    static constexpr int KK = KS * KS;
+    static constexpr int NG = TH * TW / 32;
+    static constexpr int WM = MT / 32;
+    static constexpr int WN = NG / 4;
+    static constexpr int TH_in = (TH - 1) * S + KS, TW_in = (TW - 1) * S + KS;
+    static constexpr int XS0 = (KS == 3) ? 3 : 0;             // tile column 0 = image column w0*S - pad - XS0
+    static constexpr int TWq = ((XS0 + TW_in + 3) / 4) * 4;
+    static constexpr int CSX = TH_in * TWq;                   // channel pitch
+    static constexpr int XS = CK * CSX;
+    static constexpr int WS = KK * CK * MT;
+    static constexpr int BUF = XS + WS;
+    static constexpr int NPIECE = CSX / 4;                    // 16-B pieces per input channel
+    static constexpr int NPASS = (NPIECE + 63) / 64;
+    static constexpr int NWP = WS / 4;                        // 16-B pieces of the weight slice
+    static constexpr int NWPASS = (NWP + 255) / 256;          // per wave
+    static constexpr int CPW = CK / 4;                        // input channels per wave
+    static constexpr int NS = KK * (CK / 2);                  // MFMA k-steps per chunk
+    static constexpr int LDS_BYTES = 2 * BUF * 4;
+    static_assert(WN >= 1 && WN * 4 == NG, "pixel groups must split over the 4 waves");
+    static_assert(CK % 4 == 0 && BUF % 4 == 0 && XS % 4 == 0 && CSX % 4 == 0, "16-B LDS slabs");
+};
+
+__device__ __forceinline__ i32x4 make_rsrc(const float* base, unsigned bytes) {
+    const unsigned long long b = (unsigned long long)base;
+    i32x4 r;
+    r[0] = (int)(unsigned)(b & 0xffffffffull);
+    r[1] = (int)(unsigned)((b >> 32) & 0xffffull);
+    r[2] = (int)bytes;
+    r[3] = 0x00020000;
+    return r;
+}
+
+// One 64-lane LDS-DMA: lane l copies 16 B from rsrc.base + voff[l] to LDS byte lds_base + 16*l.
+__device__ __forceinline__ void dma16(unsigned lds_base, unsigned voff, i32x4 rsrc) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :: "s"(lds_base), "v"(voff), "s"(rsrc) : "memory");
+}
+
+template <int KS, int S, int MT, int TH, int TW, int CK>
+__global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
+    using Cfg = DmaCfg<KS, S, MT, TH, TW, CK>;
+    constexpr int KK = Cfg::KK, WM = Cfg::WM, WN = Cfg::WN, TH_in = Cfg::TH_in, TWq = Cfg::TWq, CSX = Cfg::CSX,
+                  XS0 = Cfg::XS0, NPIECE = Cfg::NPIECE, NPASS = Cfg::NPASS, NWP = Cfg::NWP, NWPASS = Cfg::NWPASS,
+                  CPW = Cfg::CPW, NS = Cfg::NS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int rr = id >> 3;
+    const int ct = rr % a.nct;
+    const int pt = (rr / a.nct) * 8 + xcd;
+    if (pt >= a.npt) return;
+    const int tiles_per_img = a.tiles_h * a.tiles_w;
+    const int n = pt / tiles_per_img;
+    const int trem = pt - n * tiles_per_img;
+    const int h0 = (trem / a.tiles_w) * TH;
+    const int w0 = (trem % a.tiles_w) * TW;
+    const int co0 = ct * MT;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hbase = h0 * S - a.pad_h, wal0 = w0 * S - a.pad_w - XS0;
+    const int nchunk = (a.Cin + CK - 1) / CK;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+
+    // ---- per-lane source coordinates of the input pieces: voffset = hrow * (4*sH of the source) + wcol4 ----
+    // (padding / out-of-tile pieces: hrow = 0, wcol4 = 2^31 -> beyond the descriptor -> zeros in LDS)
+    unsigned hrow[NPASS], wcol4[NPASS];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int q = p * 64 + lane;
+        const int hh = q / (TWq / 4), j = q % (TWq / 4);
+        const int hi = hbase + hh, wi = wal0 + 4 * j;
+        const bool ok = q < NPIECE && hi >= 0 && hi < a.Hin && wi >= 0 && wi + 3 < a.Win;
+        hrow[p] = ok ? (unsigned)hi : 0u;
+        wcol4[p] = ok ? (unsigned)(wi * 4) : 0x80000000u;
+    }
+    // ---- per-lane offsets of the weight pieces: LDS order [tap][cl][m], source w[(cl*KK+tap)*CoutPad + m] ----
+    unsigned woff[NWPASS];
+#pragma unroll
+    for (int i = 0; i < NWPASS; ++i) {
+        const int q = (wave + 4 * i) * 64 + lane;
+        const int m4 = q % (MT / 4), t2 = q / (MT / 4);
+        const int cl = t2 % CK, tap = t2 / CK;
+        woff[i] = (unsigned)(((cl * KK + tap) * a.CoutPad + m4 * 4) * 4);
+    }
+
+    auto issue_chunk = [&](int k) {
+        const int c0 = k * CK;
+        const unsigned xs_b = lds0 + (unsigned)((k & 1) * Cfg::BUF * 4);
+        const unsigned ws_b = xs_b + Cfg::XS * 4;
+        // weights: rows of channels >= Cin are out of range of the descriptor -> zeros
+        {
+            const float* wb = a.w + (long long)c0 * KK * a.CoutPad + co0;
+            const i32x4 wr = make_rsrc(wb, (unsigned)(((long long)(a.Cin - c0) * KK * a.CoutPad - co0) * 4));
+#pragma unroll
+            for (int i = 0; i < NWPASS; ++i) {
+                const int pp = wave + 4 * i;
+                if ((pp + 1) * 64 <= NWP) dma16(ws_b + pp * 1024, woff[i], wr);
+                else if (pp * 64 + lane < NWP) dma16(ws_b + pp * 1024, woff[i], wr);
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < CPW; ++cc) {
+            const int cl = wave + 4 * cc;
+            const int ci = c0 + cl;                       // wave-uniform
+            if (ci >= a.Cin) {
+                float* z = smem + (k & 1) * Cfg::BUF + cl * CSX;
+                for (int e = lane; e < CSX; e += 64) z[e] = 0.f;
+                continue;
+            }
+            const int si = (ci >= a.c1) + (ci >= a.c2);
+            const int clc = ci - (si == 0 ? 0 : (si == 1 ? a.c1 : a.c2));
+            const float* sp = si == 0 ? a.src[0].p : (si == 1 ? a.src[1].p : a.src[2].p);
+            const long long sN = si == 0 ? a.src[0].sN : (si == 1 ? a.src[1].sN : a.src[2].sN);
+            const long long sC = si == 0 ? a.src[0].sC : (si == 1 ? a.src[1].sC : a.src[2].sC);
+            const unsigned sH4 = (unsigned)(si == 0 ? a.src[0].sH : (si == 1 ? a.src[1].sH : a.src[2].sH)) * 4u;
+            const i32x4 xr = make_rsrc(sp + (long long)n * sN + (long long)clc * sC, 0x7FFFFFF0u);
+            const unsigned cb = xs_b + (unsigned)(cl * CSX * 4);
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) {
+                const unsigned vo = hrow[p] * sH4 + wcol4[p];
+                if ((p + 1) * 64 <= NPIECE) dma16(cb + p * 1024, vo, xr);
+                else if (p * 64 + lane < NPIECE) dma16(cb + p * 1024, vo, xr);
+            }
+        }
+    };
+
+    const int khalf = lane >> 5, l31 = lane & 31;
+    int boff[WN];
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) {
+        const int pix = (wave * WN + ni) * 32 + l31;
+        const int r = pix / TW, c = pix % TW;
+        boff[ni] = khalf * CSX + (r * S) * TWq + c * S + XS0;
+    }
+    const int aoff = khalf * MT + l31;
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    if (a.dbg != 1) issue_chunk(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    for (int k = 0; k < nchunk; ++k) {
+        if (k + 1 < nchunk && a.dbg != 1) issue_chunk(k + 1);     // buffer (k+1)&1 was released by the last barrier
+        const float* Xs = smem + (k & 1) * Cfg::BUF;
+        const float* Ws = Xs + Cfg::XS;
+        const int cleft = a.Cin - k * CK;
+        const int npair = ((cleft < CK ? cleft : CK) + 1) >> 1;
+        if (a.dbg == 2) {
+        } else if (npair == CK / 2) {
+            // software-pipelined: the LDS operands of step s+1 are read before the MFMAs of step s
+            float av[WM], bv[WN];
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi) av[mi] = Ws[aoff + mi * 32];
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni) bv[ni] = Xs[boff[ni]];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                float avn[WM], bvn[WN];
+                if (s + 1 < NS) {
+                    const int tap = (s + 1) / (CK / 2), kk = (s + 1) % (CK / 2);
+                    const int toff = (tap / KS) * TWq + (tap % KS);
+#pragma unroll
+                    for (int mi = 0; mi < WM; ++mi) avn[mi] = Ws[(tap * CK + 2 * kk) * MT + aoff + mi * 32];
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni) bvn[ni] = Xs[2 * kk * CSX + toff + boff[ni]];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + 1 < NS) {
+#pragma unroll
+                    for (int mi = 0; mi < WM; ++mi) av[mi] = avn[mi];
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni) bv[ni] = bvn[ni];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int tap = 0; tap < KK; ++tap) {
+                const int toff = (tap / KS) * TWq + (tap % KS);
+                for (int kk = 0; kk < npair; ++kk) {
+                    float av[WM], bv[WN];
+#pragma unroll
+                    for (int mi = 0; mi < WM; ++mi) av[mi] = Ws[(tap * CK + 2 * kk) * MT + aoff + mi * 32];
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni) bv[ni] = Xs[2 * kk * CSX + toff + boff[ni]];
+#pragma unroll
+                    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < WN; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+                }
+            }
+        }
+        // chunk k consumed by this wave, its share of chunk k+1 landed -> everyone's did after the barrier
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
+    // ---------------- epilogue: bias, (eval) BatchNorm+activation, up to three destination segments -----
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            const int cc = co < a.Cout ? co : a.Cout - 1;
+            const float b = a.bias ? a.bias[cc] : 0.f;
+            float esc = 1.f, esh = 0.f, eslope = 1.f;
+            if (a.epi) { esc = a.epi[2 * cc]; esh = a.epi[2 * cc + 1]; eslope = a.epi_slope; }
+            const int seg = (co >= a.d1) + (co >= a.d2);
+            const int cod = co - (seg == 0 ? 0 : (seg == 1 ? a.d1 : a.d2));
+            float* dp = seg == 0 ? a.dst[0].p : (seg == 1 ? a.dst[1].p : a.dst[2].p);
+            const long long dN = seg == 0 ? a.dst[0].sN : (seg == 1 ? a.dst[1].sN : a.dst[2].sN);
+            const long long dC = seg == 0 ? a.dst[0].sC : (seg == 1 ? a.dst[1].sC : a.dst[2].sC);
+            const long long dH = seg == 0 ? a.dst[0].sH : (seg == 1 ? a.dst[1].sH : a.dst[2].sH);
+            const int dacc = seg == 0 ? a.dst[0].accumulate : (seg == 1 ? a.dst[1].accumulate : a.dst[2].accumulate);
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni) {
+                const int pix = (wave * WN + ni) * 32 + l31;
+                const int ho = h0 + pix / TW, wo = w0 + pix % TW;
+                const float v = acc[mi][ni][r] + b;
+                acc[mi][ni][r] = v;
+                if (co < a.Cout && ho < a.Hout && wo < a.Wout && dp) {
+                    float* q = dp + (long long)n * dN + (long long)cod * dC + (long long)ho * dH + wo;
+                    const float y = act_apply(fmaf(v, esc, esh), eslope);
+                    *q = dacc ? *q + y : y;
+                }
+            }
+        }
+    }
+    // ---------------- BatchNorm partial statistics (training) -------------------------------------------------
+    if (a.part) {
+        __syncthreads();
+        float* red = smem;                     // [4 waves][MT][2]
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni) {
+                    const int pix = (wave * WN + ni) * 32 + l31;
+                    const int ho = h0 + pix / TW, wo = w0 + pix % TW;
+                    if (ho < a.Hout && wo < a.Wout) {
+                        const float v = acc[mi][ni][r];
+                        s1 += v;
+                        s2 = fmaf(v, v, s2);
+                    }
+                }
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) {
+                    s1 += __shfl_xor(s1, off, 64);
+                    s2 += __shfl_xor(s2, off, 64);
+                }
+                if (l31 == 0) {
+                    const int m = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    red[(wave * MT + m) * 2 + 0] = s1;
+                    red[(wave * MT + m) * 2 + 1] = s2;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < MT) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                s1 += red[(w * MT + tid) * 2 + 0];
+                s2 += red[(w * MT + tid) * 2 + 1];
+            }
+            const int co = co0 + tid;
+            if (co < a.Cout) {
+                a.part[((long long)pt * a.Cout + co) * 2 + 0] = s1;
+                a.part[((long long)pt * a.Cout + co) * 2 + 1] = s2;
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------
+template <int KS, int S, int MT, int TH, int TW, int CK>
+static void dma_launch(const ConvArgs& a, hipStream_t st) {
+    using Cfg = DmaCfg<KS, S, MT, TH, TW, CK>;
+    auto kern = conv_dma_kernel<KS, S, MT, TH, TW, CK>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   Cfg::LDS_BYTES));
+        attr_set = true;
+    }
+    const int groups = (a.npt + 7) / 8;
+    const int grid = groups * 8 * a.nct;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::LDS_BYTES, st, a);
+    VR_HIP(hipGetLastError());
+}
+
+static bool src_plain(const ConvSrc& s) {
+    return !s.aff0 && !s.aff1 && !s.post && !s.up && !s.zins && s.slope == 1.f;
+}
+
+// True when the launch can take the LDS-DMA kernel; fills the tile choice.
+bool dma_pick(const ConvArgs& a, const ConvShape& s, int* MT_out, int* TH_out) {
+    static const int enabled = getenv("VR_CONV_DMA") ? atoi(getenv("VR_CONV_DMA")) : 1;
+    if (!enabled) return false;
+    if (s.dil_h != 1 || s.dil_w != 1) return false;
+    if (!((s.KS == 3 && (s.stride == 1 || s.stride == 2)) || (s.KS == 1 && s.stride == 1))) return false;
+    const int pad = s.KS == 3 ? 1 : 0;
+    if (a.pad_h != pad || a.pad_w != pad) return false;
+    if (a.Wout < 32 || (a.Win & 3)) return false;
+    for (int i = 0; i < a.nsrc; ++i) {
+        const ConvSrc& c = a.src[i];
+        if (!src_plain(c) || c.W != a.Win) return false;
+        if ((long long)c.H * (c.sH > 0 ? c.sH : 1) * 4 >= 0x7FFFFFF0LL) return false;
+    }
+    if ((long long)a.Cin * s.KS * s.KS * a.CoutPad * 4 >= 0x7FFFFFF0LL) return false;
+    int MT = (a.CoutPad % 128 == 0) ? 128 : ((a.CoutPad % 64 == 0) ? 64 : 32);
+    if (s.stride == 2 && MT == 128) MT = 64;
+    const long long tiles = (long long)a.N * ((a.Hout + 7) / 8) * ((a.Wout + 31) / 32);
+    while (MT > 32 && tiles * (a.CoutPad / MT) < 768) MT /= 2;
+    if (tiles * (a.CoutPad / MT) < 64) return false;
+    int TH = 8;
+    if (MT == 32 && s.stride == 1) {
+        const long long tiles16 = (long long)a.N * ((a.Hout + 15) / 16) * ((a.Wout + 31) / 32);
+        if (tiles16 * (a.CoutPad / 32) >= 1024) TH = 16;
+    }
+    *MT_out = MT;
+    *TH_out = TH;
+    return true;
+}
+
+void dma_launch_conv(const ConvArgs& a, const ConvShape& s, int MT, int TH, hipStream_t st) {
+    if (s.KS == 3 && s.stride == 1) {
+        if (MT == 128) dma_launch<3, 1, 128, 8, 32, 4>(a, st);
+        else if (MT == 64) dma_launch<3, 1, 64, 8, 32, 8>(a, st);
+        else if (TH == 16) dma_launch<3, 1, 32, 16, 32, 8>(a, st);
+        else dma_launch<3, 1, 32, 8, 32, 8>(a, st);
+    } else if (s.KS == 3) {
+        if (MT == 64) dma_launch<3, 2, 64, 8, 32, 4>(a, st);
+        else dma_launch<3, 2, 32, 8, 32, 4>(a, st);
+    } else {
+        if (MT == 128) dma_launch<1, 1, 128, 8, 32, 16>(a, st);
+        else if (MT == 64) dma_launch<1, 1, 64, 8, 32, 16>(a, st);
+        else if (TH == 16) dma_launch<1, 1, 32, 16, 32, 16>(a, st);
+        else dma_launch<1, 1, 32, 8, 32, 16>(a, st);
+    }
+}
+
+}  // namespace vr

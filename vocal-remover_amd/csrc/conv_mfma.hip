@@ -218,6 +218,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + (wm * WM + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
             const float b = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+            float esc = 1.f, esh = 0.f, eslope = 1.f;      // eval: folded BatchNorm + activation
+            if (a.epi) {
+                const int cc = co < a.Cout ? co : a.Cout - 1;
+                esc = a.epi[2 * cc]; esh = a.epi[2 * cc + 1]; eslope = a.epi_slope;
+            }
             const int seg = (co >= a.d1) + (co >= a.d2);
             const int cod = co - (seg == 0 ? 0 : (seg == 1 ? a.d1 : a.d2));
             ConvDst d;      // field-wise select: a dynamic index into the kernarg would go through scratch
@@ -234,7 +239,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                 acc[mi][ni][r] = v;
                 if (co < a.Cout && ho < a.Hout && wo < a.Wout && d.p) {
                     float* q = d.p + (long long)n * d.sN + (long long)cod * d.sC + (long long)ho * d.sH + wo;
-                    *q = d.accumulate ? *q + v : v;
+                    const float y = act_apply(fmaf(v, esc, esh), eslope);
+                    *q = d.accumulate ? *q + y : y;
                 }
             }
         }
@@ -314,11 +320,14 @@ static TileChoice pick_tile(const ConvArgs& a, const ConvShape& s) {
 }
 
 bool ws_pick(const ConvArgs& a, const ConvShape& s, int* MT_out, int* TH_out);
+bool dma_pick(const ConvArgs& a, const ConvShape& s, int* MT_out, int* TH_out);
+void dma_launch_conv(const ConvArgs& a, const ConvShape& s, int MT, int TH, hipStream_t st);
 void ws_fill_tiling(ConvArgs& a, int MT, int TH);
 void ws_launch_conv(const ConvArgs& a, const ConvShape& s, int MT, int TH, hipStream_t st);
 
 void conv_fill_tiling(ConvArgs& a, const ConvShape& s) {
     int wmt, wth;
+    if (dma_pick(a, s, &wmt, &wth)) { ws_fill_tiling(a, wmt, wth); return; }
     if (ws_pick(a, s, &wmt, &wth)) { ws_fill_tiling(a, wmt, wth); return; }
     TileChoice t = pick_tile(a, s);
     a.tiles_w = (a.Wout + t.TW - 1) / t.TW;
@@ -374,6 +383,12 @@ double launch_conv(const ConvArgs& a_in, const ConvShape& s, hipStream_t st) {
     a.dbg = dbg;
     {
         int wmt, wth;
+        if (dma_pick(a, s, &wmt, &wth)) {
+            VR_CHECK(a.nsrc >= 1 && a.nsrc <= 3, -2, "conv takes 1..3 sources");
+            ws_fill_tiling(a, wmt, wth);
+            dma_launch_conv(a, s, wmt, wth, st);
+            return 2.0 * a.N * (double)a.Hout * a.Wout * (double)a.Cout * a.Cin * s.KS * s.KS;
+        }
         if (ws_pick(a, s, &wmt, &wth)) {
             VR_CHECK(a.nsrc >= 1 && a.nsrc <= 3, -2, "conv takes 1..3 sources");
             ws_fill_tiling(a, wmt, wth);

@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_ws_kernel(const ConvArgs 
 
     if (wave >= 4) {
         // =========================== producers ===========================================================
+        if (a.dbg == 5) __builtin_amdgcn_s_setprio(3);
         const int pw = wave - 4, ptid = tid - 256;
         float* scratch = smem + 2 * Cfg::BUF + SG::TAB + pw * SG::NL;
         constexpr int M4 = MT / 4;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_ws_kernel(const ConvArgs 
 
     // =============================== consumers ===============================================================
     // static priority: the MFMA waves win issue arbitration over the producer waves sharing their SIMD
-    if (a.dbg != 4) __builtin_amdgcn_s_setprio(2);
+    if (a.dbg != 4 && a.dbg != 5) __builtin_amdgcn_s_setprio(2);
     const int khalf = lane >> 5, l31 = lane & 31;
     int boff[WN];
 #pragma unroll
@@ -205,6 +206,11 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_ws_kernel(const ConvArgs 
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
             const float b = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+            float esc = 1.f, esh = 0.f, eslope = 1.f;      // eval: folded BatchNorm + activation
+            if (a.epi) {
+                const int cc = co < a.Cout ? co : a.Cout - 1;
+                esc = a.epi[2 * cc]; esh = a.epi[2 * cc + 1]; eslope = a.epi_slope;
+            }
             const int seg = (co >= a.d1) + (co >= a.d2);
             const int cod = co - (seg == 0 ? 0 : (seg == 1 ? a.d1 : a.d2));
             float* dp = seg == 0 ? a.dst[0].p : (seg == 1 ? a.dst[1].p : a.dst[2].p);
@@ -220,7 +226,8 @@ __global__ __launch_bounds__(256 + 64 * NPW) void conv_ws_kernel(const ConvArgs 
                 acc[mi][ni][r] = v;
                 if (co < a.Cout && ho < a.Hout && wo < a.Wout && dp) {
                     float* q = dp + (long long)n * dN + (long long)cod * dC + (long long)ho * dH + wo;
-                    *q = dacc ? *q + v : v;
+                    const float y = act_apply(fmaf(v, esc, esh), eslope);
+                    *q = dacc ? *q + y : y;
                 }
             }
         }

@@ -224,6 +224,7 @@ private:
     template <class F> void for_each_conv(F&& f);
     Tensor run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, const Tensor* out_view);
     Tensor run_lstm(LSTMMod& M, const Tensor& h);
+    SrcSpec upsampled(const Tensor& t);
     Tensor run_net(const Tensor& x);                     // -> stg3 dec1 output (raw + affine)
     void tap(const std::string& name, const Tensor& t);
     bool dry = false;

@@ -455,6 +455,11 @@ Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs, int N, const T
     ConvArgs a;
     build_fwd_args(L, srcs, N, batch_as_h, a);
     a.bias = bias;
+    // Eval: the folded BatchNorm + activation go into the conv's epilogue, so the stored tensor is the
+    // final activation and its consumers load it with no arithmetic (conv_dma.hip).  Training keeps
+    // the raw tensor + pending affine: the batch statistics only exist after the whole conv has run.
+    const bool fuse_epi = !training && L.bn != nullptr && !batch_as_h;   // (the LSTM dense layer applies its own)
+    if (fuse_epi) { a.epi = L.bn->affine; a.epi_slope = L.slope; }
     Tensor o;
     if (batch_as_h) {
         o.N = N; o.C = L.Cout; o.H = 1; o.W = a.Wout;
@@ -499,7 +504,7 @@ Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs, int N, const T
             L.bn->nbt->nbt += 1;
         }
     }
-    if (L.bn) { o.aff0 = L.bn->affine; o.slope = L.slope; } else { o.aff0 = nullptr; o.slope = 1.f; }
+    if (L.bn && !fuse_epi) { o.aff0 = L.bn->affine; o.slope = L.slope; } else { o.aff0 = nullptr; o.slope = 1.f; }
     if (training) {
         TapeRec r;
         r.kind = TK_CONV; r.L = &L; r.srcs = srcs; r.out = o; r.N = N; r.batch_as_h = batch_as_h; r.bias = bias;
@@ -573,6 +578,22 @@ Tensor Model::run_lstm(LSTMMod& M, const Tensor& h) {
     return o;
 }
 
+// Decoder input (lib/layers.py:52): training fuses the x2 bilinear upsample into the consuming conv's
+// loader; eval materialises it once (HBM-bound, small) so the conv reads a plain tensor by LDS-DMA.
+Model::SrcSpec Model::upsampled(const Tensor& t) {
+    if (training) {
+        SrcSpec s{t};
+        s.up = true;
+        return s;
+    }
+    Tensor u;
+    u.N = t.N; u.C = t.C; u.H = 2 * t.H; u.W = 2 * t.W;
+    u.sH = u.W; u.sC = (long long)u.H * u.W; u.sN = u.sC * u.C; u.slope = 1.f;
+    u.p = ws.allocf((size_t)u.N * u.C * u.H * u.W);
+    if (!dry) launch_upsample2x(t, u.p, stream);
+    return SrcSpec{u};
+}
+
 // nets.BaseNet.__call__ (lib/nets.py:26-41)
 Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, const Tensor* out_view) {
     const std::string& p = B.prefix;
@@ -605,7 +626,7 @@ Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, co
     cat4.sH = x5.W; cat4.sC = (long long)x5.H * x5.W; cat4.sN = cat4.sC * cat4.C;
     cat4.p = ws.allocf((size_t)N * cat4.C * x5.H * x5.W);
     if (training) cat4.g = gs.allocf((size_t)N * cat4.C * x5.H * x5.W);
-    cat4.aff0 = B.aspp_aff; cat4.slope = 0.f;
+    if (training) { cat4.aff0 = B.aspp_aff; cat4.slope = 0.f; }      // eval: the branch convs store final activations
     Conv* branch[4] = {&B.aspp_c2, &B.aspp_d[0], &B.aspp_d[1], &B.aspp_d[2]};
     for (int j = 0; j < 4; ++j) {
         Tensor v = cat4;
@@ -625,15 +646,14 @@ Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, co
     tap(p + ".aspp", h);
     // decoders (lib/layers.py:51-64): upsample x2 + skip concat + conv, all inside the conv's loader
     for (int i = 0; i < 3; ++i) {
-        SrcSpec up{h};
-        up.up = true;
+        SrcSpec up = upsampled(h);
         h = run_conv(B.dec[i], {up, SrcSpec{e[3 - i]}}, N, nullptr, nullptr, false);
         tap(p + ".dec" + std::to_string(4 - i), h);
     }
     Tensor l = run_lstm(B.lstm, h);
     tap(p + ".lstm", l);
-    SrcSpec uh{h}; uh.up = true;
-    SrcSpec ul{l}; ul.up = true;
+    SrcSpec uh = upsampled(h);
+    SrcSpec ul = upsampled(l);
     Tensor o = run_conv(B.dec[3], {uh, ul, SrcSpec{e[0]}}, N, out_view, nullptr, false);
     tap(p + ".dec1", o);
     return o;
@@ -651,7 +671,7 @@ Tensor Model::run_net(const Tensor& x) {
         t.sH = T; t.sC = (long long)max_bin * T; t.sN = t.sC * C;
         t.p = ws.allocf((size_t)B * C * max_bin * T);
         if (training) t.g = gs.allocf((size_t)B * C * max_bin * T);
-        t.slope = 0.f;
+        t.slope = training ? 0.f : 1.f;     // eval: dec1 / the tail convs store final activations
         return t;
     };
     Tensor aux1 = make_aux(nout / 4), aux2 = make_aux(nout / 2);

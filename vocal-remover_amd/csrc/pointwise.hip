@@ -234,6 +234,44 @@ __global__ void materialize_kernel(Tensor x, float* out, long long total) {
     out[gid] = act1(fmaf(raw, sc, sh), x.slope);
 }
 
+// Bilinear x2 upsample, align_corners=True (lib/layers.py:52 F.interpolate), of the activated tensor
+// into a dense [N][C][2H][2W] buffer: eval mode materialises the decoder's upsampled input once so
+// that the consuming conv can take the LDS-DMA path (plain input, no arithmetic in the loader).
+// Same arithmetic (tap weights and summation order) as the fused loader in conv_stage.h.
+__global__ void upsample2x_kernel(Tensor x, float* out, float rh, float rw, long long total) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int W2 = 2 * x.W, H2 = 2 * x.H;
+    const int wi = (int)(gid % W2);
+    long long t = gid / W2;
+    const int hi = (int)(t % H2); t /= H2;
+    const int c = (int)(t % x.C);
+    const int n = (int)(t / x.C);
+    const float h1r = rh * (float)hi, w1r = rw * (float)wi;
+    const int h1 = (int)h1r, w1 = (int)w1r;
+    const int h1p = (h1 < x.H - 1) ? 1 : 0, w1p = (w1 < x.W - 1) ? 1 : 0;
+    const float h1l = h1r - (float)h1, w1l = w1r - (float)w1;
+    const float h0l = 1.f - h1l, w0l = 1.f - w1l;
+    const float* q0 = x.p + (long long)n * x.sN + (long long)c * x.sC + (long long)h1 * x.sH + w1;
+    const float* q1 = q0 + (long long)h1p * x.sH;
+    float sc0, sh0, sc1, sh1;
+    load_aff(x, h1, c, sc0, sh0);
+    load_aff(x, h1 + h1p, c, sc1, sh1);
+    const float v00 = act1(fmaf(q0[0], sc0, sh0), x.slope);
+    const float v01 = act1(fmaf(q0[w1p], sc0, sh0), x.slope);
+    const float v10 = act1(fmaf(q1[0], sc1, sh1), x.slope);
+    const float v11 = act1(fmaf(q1[w1p], sc1, sh1), x.slope);
+    out[gid] = h0l * (w0l * v00 + w1l * v01) + h1l * (w0l * v10 + w1l * v11);
+}
+
+void launch_upsample2x(const Tensor& x, float* out, hipStream_t st) {
+    const long long total = (long long)x.N * x.C * x.H * x.W * 4;
+    const float rh = (x.H > 0) ? (float)(x.H - 1) / (float)(2 * x.H - 1) : 0.f;
+    const float rw = (x.W > 0) ? (float)(x.W - 1) / (float)(2 * x.W - 1) : 0.f;
+    hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, out, rh, rw, total);
+    VR_HIP(hipGetLastError());
+}
+
 void launch_materialize(const Tensor& x, float* out, hipStream_t st) {
     const long long total = (long long)x.N * x.C * x.H * x.W;
     hipLaunchKernelGGL(materialize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, out, total);

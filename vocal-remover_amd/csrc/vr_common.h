@@ -92,6 +92,8 @@ struct ConvArgs {
     ConvDst dst[3];
     int d1, d2;                // dst0 = output channels [0,d1), dst1 = [d1,d2), dst2 = [d2,Cout)
     float* part;               // per-block BatchNorm partials [npt][Cout][2] (sum, sumsq) or null
+    const float* epi;          // eval mode: folded BatchNorm [Cout][2] (scale, shift) applied in the epilogue
+    float epi_slope;           //            together with the activation, so the stored tensor is final
     int N, Hout, Wout, Hin, Win;
     int pad_h, pad_w;
     int tiles_w, tiles_h, npt, nct;

@@ -137,6 +137,189 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradArgs a) {
     }
 }
 
+// Warp-specialised variant (same split as conv_ws.hip): waves 0..3 only run the MFMA loop on the
+// current (dz, input) tile pair, waves 4..4+NPW-1 stage the NEXT pixel tile into the other LDS
+// buffer; one workgroup barrier per pixel tile.
+template <int KS, int S, int TH, int TW, int MB>
+struct WgWsCfg {
+    using B = WgCfg<KS, S, 1, 1, TH, TW, MB>;
+    static constexpr int BUF = B::XS + B::DS;          // floats per buffer
+    static constexpr int LDS_BYTES = 2 * BUF * 4;
+};
+
+// Consumer wave of wgrad_ws_kernel.  The four consumer waves are (sel = wave>>1, HALF = wave&1):
+//   HALF picks the tap group (taps 0..4 or 5..8, compile time, so every LDS read below is
+//   base + immediate), sel picks the 32-cout block (MB == 2) or the half of the tile's rows
+//   (MB == 1; the two row-halves are summed through LDS at the end).  One dz fragment feeds all taps
+//   of a k-step and the fragments of step k+1 are read before the MFMAs of step k are issued.
+template <int KS, int S, int TH, int TW, int MB, int HALF>
+__device__ __forceinline__ void wg_consumer(const WgradArgs& a, float* smem, int sel, int lane, int p, int co0, int c0,
+                                            int ntiles) {
+    using Cfg = WgCfg<KS, S, 1, 1, TH, TW, MB>;
+    using Ws = WgWsCfg<KS, S, TH, TW, MB>;
+    constexpr int KK = Cfg::KK, TW_in = Cfg::TW_in, CS = Cfg::CS, DSs = Cfg::DSs;
+    constexpr int T0 = HALF * 5, NTAP = HALF ? KK - 5 : 5;
+    constexpr int ROWS = MB == 2 ? TH : TH / 2;
+    static_assert(KS == 3 && (MB == 1 || MB == 2), "tap grouping is written for 3x3 kernels");
+    const int khalf = lane >> 5, l31 = lane & 31;
+    const int rbeg = MB == 2 ? 0 : sel * ROWS;
+    const int doff = (MB == 2 ? sel * 32 * DSs : 0) + l31 * DSs + khalf;
+    const int xoff = l31 * CS + khalf * S;
+
+    f32x16 acc[NTAP];
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    __syncthreads();                         // first tile staged
+    for (int it = 0; it < ntiles; ++it) {
+        const float* Xs = smem + (it & 1) * Ws::BUF;
+        const float* Ds = Xs + Cfg::XS;
+        if (!(a.in.dbg & 1)) {
+            const float* dr = Ds + doff + rbeg * TW;
+            const float* xr = Xs + xoff + rbeg * S * TW_in;
+            float av = dr[0], bv[NTAP];
+#pragma unroll
+            for (int t = 0; t < NTAP; ++t) bv[t] = xr[((T0 + t) / KS) * TW_in + (T0 + t) % KS];
+#pragma unroll 1
+            for (int r = 0; r < ROWS; ++r) {
+                const int rn = r + 1 < ROWS ? r + 1 : r;
+                const float* drn = Ds + doff + (rbeg + rn) * TW;
+                const float* xrn = Xs + xoff + (rbeg + rn) * S * TW_in;
+#pragma unroll
+                for (int cc = 0; cc < TW / 2; ++cc) {
+                    float avn, bvn[NTAP];
+                    if (cc + 1 < TW / 2) {
+                        avn = dr[2 * (cc + 1)];
+#pragma unroll
+                        for (int t = 0; t < NTAP; ++t)
+                            bvn[t] = xr[2 * (cc + 1) * S + ((T0 + t) / KS) * TW_in + (T0 + t) % KS];
+                    } else {
+                        avn = drn[0];
+#pragma unroll
+                        for (int t = 0; t < NTAP; ++t) bvn[t] = xrn[((T0 + t) / KS) * TW_in + (T0 + t) % KS];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);       // keep the reads of step k+1 ahead of the MFMAs of step k
+#pragma unroll
+                    for (int t = 0; t < NTAP; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    av = avn;
+#pragma unroll
+                    for (int t = 0; t < NTAP; ++t) bv[t] = bvn[t];
+                }
+                dr = drn;
+                xr = xrn;
+            }
+        }
+        __syncthreads();                     // done with this tile; the next one is staged
+    }
+    if (MB == 1) {                           // sum the two row-halves (sel 1 -> LDS -> sel 0)
+        float* red = smem;
+        if (sel == 1) {
+#pragma unroll
+            for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((T0 + t) * 16 + r) * 64 + lane] = acc[t][r];
+        }
+        __syncthreads();
+        if (sel == 1) return;
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] += red[((T0 + t) * 16 + r) * 64 + lane];
+    }
+    float* pp = a.part + (long long)p * a.part_stride;
+    const int ci = c0 + l31;
+    const int mb = MB == 2 ? sel : 0;
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            if (ci < a.in.Cin && co < a.CoutPad) pp[((long long)ci * KK + (T0 + t)) * a.CoutPad + co] = acc[t][r];
+        }
+    }
+}
+
+template <int KS, int S, int TH, int TW, int MB, int NPW>
+__global__ __launch_bounds__(256 + 64 * NPW) void wgrad_ws_kernel(const WgradArgs a) {
+    using Cfg = WgCfg<KS, S, 1, 1, TH, TW, MB>;
+    using Ws = WgWsCfg<KS, S, TH, TW, MB>;
+    constexpr int KK = Cfg::KK, TP = Cfg::TP, TH_in = Cfg::TH_in, TW_in = Cfg::TW_in, CS = Cfg::CS, DSs = Cfg::DSs,
+                  NT = Cfg::NT, NPT = 64 * NPW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int rr = id >> 3;
+    const int inner = a.nchunks * a.nct;
+    const int p = (rr / inner) * 8 + xcd;
+    if (p >= a.P) return;
+    const int ib = rr % inner;
+    const int ct = ib % a.nct, cb = ib / a.nct;
+    const int co0 = ct * MB * 32, c0 = cb * 32;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int khalf = lane >> 5, l31 = lane & 31;
+    const int tiles_per_img = a.tiles_h * a.tiles_w;
+    const int t_begin = (int)((long long)p * a.npt / a.P), t_end = (int)((long long)(p + 1) * a.npt / a.P);
+
+    if (wave >= 4) {
+        // ------------------------------ producers ------------------------------
+        const int pw = wave - 4, ptid = tid - 256;
+        if (a.in.dbg & 4) __builtin_amdgcn_s_setprio(3);
+        for (int pt = t_begin; pt < t_end; ++pt) {
+            float* Xs = smem + ((pt - t_begin) & 1) * Ws::BUF;
+            float* Ds = Xs + Cfg::XS;
+            if (a.in.dbg & 2) { __syncthreads(); continue; }
+            const int n = pt / tiles_per_img;
+            const int trem = pt - n * tiles_per_img;
+            const int h0 = (trem / a.tiles_w) * TH, w0 = (trem % a.tiles_w) * TW;
+            {
+                constexpr int NEL = MB * 32 * TP;
+                constexpr int NPASS = (NEL + NPT - 1) / NPT;
+                constexpr int PB = NPASS < 8 ? NPASS : 8;
+                const float* zb = a.dz + (long long)n * a.zN;
+#pragma unroll 1
+                for (int p0 = 0; p0 < NPASS; p0 += PB) {
+                    float v[PB];
+#pragma unroll
+                    for (int j = 0; j < PB; ++j) {
+                        int idx = ptid + (p0 + j) * NPT;
+                        idx = idx < NEL ? idx : NEL - 1;
+                        const int co = idx / TP, px = idx % TP;
+                        int cg = co0 + co; cg = cg < a.Cout ? cg : a.Cout - 1;
+                        int h = h0 + px / TW, w = w0 + px % TW;
+                        h = h < a.in.Hout ? h : a.in.Hout - 1;
+                        w = w < a.in.Wout ? w : a.in.Wout - 1;
+                        v[j] = zb[(long long)cg * a.zC + (long long)h * a.zH + w];
+                    }
+#pragma unroll
+                    for (int j = 0; j < PB; ++j) {
+                        const int idx = ptid + (p0 + j) * NPT;
+                        const int co = idx / TP, px = idx % TP;
+                        const bool ok = (co0 + co < a.Cout) && (h0 + px / TW < a.in.Hout) && (w0 + px % TW < a.in.Wout);
+                        if (idx < NEL) Ds[co * DSs + px] = ok ? v[j] : 0.f;
+                    }
+                }
+            }
+            stage_input_chunk<TH_in, TW_in, TW_in, CS, 32, NPW>(a.in, Xs, c0, n, h0 * S - a.in.pad_h,
+                                                                 w0 * S - a.in.pad_w, pw, lane);
+            __syncthreads();                 // tile pt staged; consumers finished tile pt-1
+        }
+        __syncthreads();                     // matches the consumers' first barrier of the next (absent) tile
+        if (MB == 1) __syncthreads();        // k-split reduction barrier of the consumers
+        return;
+    }
+    // -------------------------------- consumers --------------------------------
+    if (wave & 1) wg_consumer<KS, S, TH, TW, MB, 1>(a, smem, wave >> 1, lane, p, co0, c0, t_end - t_begin);
+    else wg_consumer<KS, S, TH, TW, MB, 0>(a, smem, wave >> 1, lane, p, co0, c0, t_end - t_begin);
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, long long stride, int P, float* __restrict__ out,
                                     long long n, int accumulate) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -146,14 +329,26 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, long long st
     out[i] = accumulate ? out[i] + s : s;
 }
 
-struct WgTile { int TH, TW, MB; };
+struct WgTile { int TH, TW, MB; bool ws; };
+
+static bool wg_ws_enabled() {
+    static const bool on = [] { const char* e = getenv("VR_WGRAD_WS"); return !e || atoi(e) != 0; }();
+    return on;
+}
 
 static WgTile wg_pick(const WgradArgs& a, const ConvShape& s) {
     WgTile t;
     const bool dilated = (s.dil_h != 1 || s.dil_w != 1);
+    const int nb = a.CoutPad / 32;
+    t.ws = wg_ws_enabled() && s.KS == 3 && !dilated;
+    if (t.ws) {
+        if (s.stride == 2) { t.TW = 16; t.TH = 4; }
+        else { t.TW = a.in.Wout >= 32 ? 32 : 16; t.TH = t.TW == 32 ? 4 : 8; }
+        t.MB = (nb % 2 == 0) ? 2 : 1;
+        return t;
+    }
     t.TW = (a.in.Wout >= 32 && !dilated) ? 32 : 16;
     t.TH = dilated ? 4 : (t.TW == 32 ? 4 : 8);
-    const int nb = a.CoutPad / 32;
     t.MB = (nb % 4 == 0) ? 4 : ((nb % 2 == 0) ? 2 : 1);
     return t;
 }
@@ -196,11 +391,42 @@ static void wg_launch_mb(const WgradArgs& a, int MB, hipStream_t st) {
     else wg_launch_inst<KS, S, DH, DW, TH, TW, 1>(a, st);
 }
 
+template <int KS, int S, int TH, int TW, int MB>
+static void wg_launch_ws_inst(const WgradArgs& a, hipStream_t st) {
+    constexpr int NPW = 8;
+    using Ws = WgWsCfg<KS, S, TH, TW, MB>;
+    auto kern = wgrad_ws_kernel<KS, S, TH, TW, MB, NPW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   Ws::LDS_BYTES));
+        attr_set = true;
+    }
+    const int grid = ((a.P + 7) / 8) * 8 * a.nchunks * a.nct;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256 + 64 * NPW), Ws::LDS_BYTES, st, a);
+    VR_HIP(hipGetLastError());
+}
+
+template <int KS, int S, int TH, int TW>
+static void wg_launch_ws(const WgradArgs& a, int MB, hipStream_t st) {
+    if (MB == 2) wg_launch_ws_inst<KS, S, TH, TW, 2>(a, st);
+    else wg_launch_ws_inst<KS, S, TH, TW, 1>(a, st);
+}
+
 double launch_wgrad(const WgradArgs& a_in, const ConvShape& s, float* grad_out, int accumulate, hipStream_t st) {
     WgradArgs a = a_in;
     wgrad_plan(a, s);
     const WgTile t = wg_pick(a, s);
     VR_CHECK(a.part != nullptr, -2, "wgrad needs a scratch slab");
+    {
+        static const int dbg = [] { const char* e = getenv("VR_WG_DBG"); return e ? atoi(e) : 0; }();
+        a.in.dbg = dbg;
+    }
+    if (t.ws) {
+        if (s.stride == 2) wg_launch_ws<3, 2, 4, 16>(a, t.MB, st);
+        else if (t.TW == 32) wg_launch_ws<3, 1, 4, 32>(a, t.MB, st);
+        else wg_launch_ws<3, 1, 8, 16>(a, t.MB, st);
+    } else
     if (s.KS == 1) {
         if (t.TW == 32) wg_launch_mb<1, 1, 1, 1, 4, 32>(a, t.MB, st); else wg_launch_mb<1, 1, 1, 1, 8, 16>(a, t.MB, st);
     } else if (s.stride == 1 && s.dil_h == 1 && s.dil_w == 1) {
