@@ -1,6 +1,6 @@
-// LDS-DMA convolution: the forward conv of lib/layers.py:12-20 (3x3 stride 1/2 and 1x1) for inputs
-// that are PLAIN tensors (no pending BatchNorm affine / activation / dropout / upsample), which is
-// every conv of the eval-mode network once the producer applies BatchNorm+activation in its epilogue.
+// LDS-DMA convolution: the forward conv of lib/layers.py:12-20 (3x3 stride 1/2, dilated 3x3, 1x1) for
+// inputs that are PLAIN tensors (no pending BatchNorm affine / activation / dropout / upsample), which
+// is every conv of the eval-mode network once the producer applies BatchNorm+activation in its epilogue.
 //
 // Why a third conv kernel: on gfx950 the fp32 MFMA and the VALU of a SIMD do not overlap
 // (tools/mfma_overlap.hip: MFMA-only 5.0 ms + VALU-only 10.7 ms = 14.7 ms together), so every VALU
@@ -23,16 +23,21 @@
 namespace vr {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+struct DmaTile { int MT, TH, TW; };
 
-template <int KS, int S, int MT, int TH, int TW, int CK>
+template <int KS, int S, int DH, int DW, int MT, int TH, int TW, int CK>
 struct DmaCfg {
     static constexpr int KK = KS * KS;
     static constexpr int NG = TH * TW / 32;
     static constexpr int WM = MT / 32;
     static constexpr int WN = NG / 4;
-    static constexpr int TH_in = (TH - 1) * S + KS, TW_in = (TW - 1) * S + KS;
-    static constexpr int XS0 = (KS == 3) ? 3 : 0;             // tile column 0 = image column w0*S - pad - XS0
-    static constexpr int TWq = ((XS0 + TW_in + 3) / 4) * 4;
+    static constexpr int TH_in = (TH - 1) * S + (KS - 1) * DH + 1;
+    static constexpr int TW_in = (TW - 1) * S + (KS - 1) * DW + 1;
+    static constexpr int PADW = DW * (KS - 1) / 2, PADH = DH * (KS - 1) / 2;
+    static constexpr int XS0 = (4 - PADW % 4) % 4;            // tile column 0 = image column w0*S - PADW - XS0 (= 0 mod 4)
+    static constexpr int TWn = ((XS0 + TW_in + 3) / 4) * 4;   // columns that carry data
+    // TW == 16: a 32-lane operand read covers two tile rows -> pitch = 16 (mod 32) keeps them on disjoint banks
+    static constexpr int TWq = (TW == 16) ? ((TWn + 15) / 32 * 32 + 16) : TWn;
     static constexpr int CSX = TH_in * TWq;                   // channel pitch
     static constexpr int XS = CK * CSX;
     static constexpr int WS = KK * CK * MT;
@@ -46,6 +51,7 @@ struct DmaCfg {
     static constexpr int LDS_BYTES = 2 * BUF * 4;
     static_assert(WN >= 1 && WN * 4 == NG, "pixel groups must split over the 4 waves");
     static_assert(CK % 4 == 0 && BUF % 4 == 0 && XS % 4 == 0 && CSX % 4 == 0, "16-B LDS slabs");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
 __device__ __forceinline__ i32x4 make_rsrc(const float* base, unsigned bytes) {
@@ -64,10 +70,16 @@ __device__ __forceinline__ void dma16(unsigned lds_base, unsigned voff, i32x4 rs
                  :: "s"(lds_base), "v"(voff), "s"(rsrc) : "memory");
 }
 
-template <int KS, int S, int MT, int TH, int TW, int CK>
+__device__ __forceinline__ void dma_wait_and_barrier() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int KS, int S, int DH, int DW, int MT, int TH, int TW, int CK>
 __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
-    using Cfg = DmaCfg<KS, S, MT, TH, TW, CK>;
-    constexpr int KK = Cfg::KK, WM = Cfg::WM, WN = Cfg::WN, TH_in = Cfg::TH_in, TWq = Cfg::TWq, CSX = Cfg::CSX,
+    using Cfg = DmaCfg<KS, S, DH, DW, MT, TH, TW, CK>;
+    constexpr int KK = Cfg::KK, WM = Cfg::WM, WN = Cfg::WN, TWq = Cfg::TWq, TWn = Cfg::TWn, CSX = Cfg::CSX,
                   XS0 = Cfg::XS0, NPIECE = Cfg::NPIECE, NPASS = Cfg::NPASS, NWP = Cfg::NWP, NWPASS = Cfg::NWPASS,
                   CPW = Cfg::CPW, NS = Cfg::NS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -87,19 +99,20 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hbase = h0 * S - a.pad_h, wal0 = w0 * S - a.pad_w - XS0;
+    const int hbase = h0 * S - Cfg::PADH, wal0 = w0 * S - Cfg::PADW - XS0;
     const int nchunk = (a.Cin + CK - 1) / CK;
+    const int nfull = a.Cin / CK;
     const unsigned lds0 = (unsigned)(size_t)smem;
 
     // ---- per-lane source coordinates of the input pieces: voffset = hrow * (4*sH of the source) + wcol4 ----
-    // (padding / out-of-tile pieces: hrow = 0, wcol4 = 2^31 -> beyond the descriptor -> zeros in LDS)
+    // (padding / pitch-filler pieces: hrow = 0, wcol4 = 2^31 -> beyond the descriptor -> zeros, no traffic)
     unsigned hrow[NPASS], wcol4[NPASS];
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
         const int q = p * 64 + lane;
         const int hh = q / (TWq / 4), j = q % (TWq / 4);
         const int hi = hbase + hh, wi = wal0 + 4 * j;
-        const bool ok = q < NPIECE && hi >= 0 && hi < a.Hin && wi >= 0 && wi + 3 < a.Win;
+        const bool ok = q < NPIECE && 4 * j < TWn && hi >= 0 && hi < a.Hin && wi >= 0 && wi + 3 < a.Win;
         hrow[p] = ok ? (unsigned)hi : 0u;
         wcol4[p] = ok ? (unsigned)(wi * 4) : 0x80000000u;
     }
@@ -124,8 +137,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < NWPASS; ++i) {
                 const int pp = wave + 4 * i;
-                if ((pp + 1) * 64 <= NWP) dma16(ws_b + pp * 1024, woff[i], wr);
-                else if (pp * 64 + lane < NWP) dma16(ws_b + pp * 1024, woff[i], wr);
+                if (pp * 64 + lane < NWP) dma16(ws_b + pp * 1024, woff[i], wr);
             }
         }
 #pragma unroll
@@ -172,19 +184,14 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     if (a.dbg != 1) issue_chunk(0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    dma_wait_and_barrier();
 
-    for (int k = 0; k < nchunk; ++k) {
+    // ---- full chunks: software-pipelined (the LDS operands of step s+1 are read before the MFMAs of step s)
+    for (int k = 0; k < nfull; ++k) {
         if (k + 1 < nchunk && a.dbg != 1) issue_chunk(k + 1);     // buffer (k+1)&1 was released by the last barrier
         const float* Xs = smem + (k & 1) * Cfg::BUF;
         const float* Ws = Xs + Cfg::XS;
-        const int cleft = a.Cin - k * CK;
-        const int npair = ((cleft < CK ? cleft : CK) + 1) >> 1;
-        if (a.dbg == 2) {
-        } else if (npair == CK / 2) {
-            // software-pipelined: the LDS operands of step s+1 are read before the MFMAs of step s
+        if (a.dbg != 2) {
             float av[WM], bv[WN];
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi) av[mi] = Ws[aoff + mi * 32];
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
                 float avn[WM], bvn[WN];
                 if (s + 1 < NS) {
                     const int tap = (s + 1) / (CK / 2), kk = (s + 1) % (CK / 2);
-                    const int toff = (tap / KS) * TWq + (tap % KS);
+                    const int toff = (tap / KS) * DH * TWq + (tap % KS) * DW;
 #pragma unroll
                     for (int mi = 0; mi < WM; ++mi) avn[mi] = Ws[(tap * CK + 2 * kk) * MT + aoff + mi * 32];
 #pragma unroll
@@ -215,10 +222,18 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
                     for (int ni = 0; ni < WN; ++ni) bv[ni] = bvn[ni];
                 }
             }
-        } else {
+        }
+        dma_wait_and_barrier();
+    }
+    // ---- the partial last chunk (Cin % CK channels; the pair's odd channel is zero-filled) ----------------
+    if (nfull < nchunk) {
+        const float* Xs = smem + (nfull & 1) * Cfg::BUF;
+        const float* Ws = Xs + Cfg::XS;
+        const int npair = (a.Cin - nfull * CK + 1) >> 1;
+        if (a.dbg != 2) {
 #pragma unroll
             for (int tap = 0; tap < KK; ++tap) {
-                const int toff = (tap / KS) * TWq + (tap % KS);
+                const int toff = (tap / KS) * DH * TWq + (tap % KS) * DW;
                 for (int kk = 0; kk < npair; ++kk) {
                     float av[WM], bv[WN];
 #pragma unroll
@@ -233,10 +248,6 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
                 }
             }
         }
-        // chunk k consumed by this wave, its share of chunk k+1 landed -> everyone's did after the barrier
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
     }
 
     // ---------------- epilogue: bias, (eval) BatchNorm+activation, up to three destination segments -----
@@ -319,10 +330,10 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------------
-template <int KS, int S, int MT, int TH, int TW, int CK>
+template <int KS, int S, int DH, int DW, int MT, int TH, int TW, int CK>
 static void dma_launch(const ConvArgs& a, hipStream_t st) {
-    using Cfg = DmaCfg<KS, S, MT, TH, TW, CK>;
-    auto kern = conv_dma_kernel<KS, S, MT, TH, TW, CK>;
+    using Cfg = DmaCfg<KS, S, DH, DW, MT, TH, TW, CK>;
+    auto kern = conv_dma_kernel<KS, S, DH, DW, MT, TH, TW, CK>;
     static bool attr_set = false;
     if (!attr_set) {
         VR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -339,50 +350,73 @@ static bool src_plain(const ConvSrc& s) {
     return !s.aff0 && !s.aff1 && !s.post && !s.up && !s.zins && s.slope == 1.f;
 }
 
-// True when the launch can take the LDS-DMA kernel; fills the tile choice.
-bool dma_pick(const ConvArgs& a, const ConvShape& s, int* MT_out, int* TH_out) {
+// True when the launch can take the LDS-DMA kernel; fills the tile choice (MT, TH, TW).
+bool dma_pick(const ConvArgs& a, const ConvShape& s, DmaTile* t) {
     static const int enabled = getenv("VR_CONV_DMA") ? atoi(getenv("VR_CONV_DMA")) : 1;
     if (!enabled) return false;
-    if (s.dil_h != 1 || s.dil_w != 1) return false;
-    if (!((s.KS == 3 && (s.stride == 1 || s.stride == 2)) || (s.KS == 1 && s.stride == 1))) return false;
-    const int pad = s.KS == 3 ? 1 : 0;
-    if (a.pad_h != pad || a.pad_w != pad) return false;
-    if (a.Wout < 32 || (a.Win & 3)) return false;
+    const bool dil = s.dil_h != 1 || s.dil_w != 1;
+    if (dil) {
+        if (!(s.KS == 3 && s.stride == 1)) return false;
+        if (!((s.dil_h == 4 && s.dil_w == 2) || (s.dil_h == 8 && s.dil_w == 4) || (s.dil_h == 12 && s.dil_w == 6)))
+            return false;
+    } else if (!((s.KS == 3 && (s.stride == 1 || s.stride == 2)) || (s.KS == 1 && s.stride == 1))) {
+        return false;
+    }
+    if (a.pad_h != s.dil_h * (s.KS - 1) / 2 || a.pad_w != s.dil_w * (s.KS - 1) / 2) return false;
+    if (a.Wout < 16 || (a.Win & 3)) return false;
     for (int i = 0; i < a.nsrc; ++i) {
         const ConvSrc& c = a.src[i];
         if (!src_plain(c) || c.W != a.Win) return false;
         if ((long long)c.H * (c.sH > 0 ? c.sH : 1) * 4 >= 0x7FFFFFF0LL) return false;
     }
     if ((long long)a.Cin * s.KS * s.KS * a.CoutPad * 4 >= 0x7FFFFFF0LL) return false;
+    if (a.Wout < 32 || dil) {
+        // 1/16-resolution layers: 16x16 pixel tiles, 32 couts per workgroup (the grids are small)
+        t->TW = 16; t->TH = 16; t->MT = 32;
+        return true;
+    }
     int MT = (a.CoutPad % 128 == 0) ? 128 : ((a.CoutPad % 64 == 0) ? 64 : 32);
     if (s.stride == 2 && MT == 128) MT = 64;
     const long long tiles = (long long)a.N * ((a.Hout + 7) / 8) * ((a.Wout + 31) / 32);
     while (MT > 32 && tiles * (a.CoutPad / MT) < 768) MT /= 2;
-    if (tiles * (a.CoutPad / MT) < 64) return false;
     int TH = 8;
     if (MT == 32 && s.stride == 1) {
         const long long tiles16 = (long long)a.N * ((a.Hout + 15) / 16) * ((a.Wout + 31) / 32);
         if (tiles16 * (a.CoutPad / 32) >= 1024) TH = 16;
     }
-    *MT_out = MT;
-    *TH_out = TH;
+    t->MT = MT; t->TH = TH; t->TW = 32;
     return true;
 }
 
-void dma_launch_conv(const ConvArgs& a, const ConvShape& s, int MT, int TH, hipStream_t st) {
-    if (s.KS == 3 && s.stride == 1) {
-        if (MT == 128) dma_launch<3, 1, 128, 8, 32, 4>(a, st);
-        else if (MT == 64) dma_launch<3, 1, 64, 8, 32, 8>(a, st);
-        else if (TH == 16) dma_launch<3, 1, 32, 16, 32, 8>(a, st);
-        else dma_launch<3, 1, 32, 8, 32, 8>(a, st);
+void dma_fill_tiling(ConvArgs& a, const DmaTile& t) {
+    a.tiles_w = (a.Wout + t.TW - 1) / t.TW;
+    a.tiles_h = (a.Hout + t.TH - 1) / t.TH;
+    a.npt = a.N * a.tiles_h * a.tiles_w;
+    a.nct = a.CoutPad / t.MT;
+}
+
+void dma_launch_conv(const ConvArgs& a, const ConvShape& s, const DmaTile& t, hipStream_t st) {
+    const int MT = t.MT, TH = t.TH;
+    if (t.TW == 16) {
+        if (s.KS == 1) dma_launch<1, 1, 1, 1, 32, 16, 16, 16>(a, st);
+        else if (s.stride == 2) dma_launch<3, 2, 1, 1, 32, 16, 16, 4>(a, st);
+        else if (s.dil_h == 1) dma_launch<3, 1, 1, 1, 32, 16, 16, 8>(a, st);
+        else if (s.dil_h == 4) dma_launch<3, 1, 4, 2, 32, 16, 16, 4>(a, st);
+        else if (s.dil_h == 8) dma_launch<3, 1, 8, 4, 32, 16, 16, 4>(a, st);
+        else dma_launch<3, 1, 12, 6, 32, 16, 16, 4>(a, st);
+    } else if (s.KS == 3 && s.stride == 1) {
+        if (MT == 128) dma_launch<3, 1, 1, 1, 128, 8, 32, 4>(a, st);
+        else if (MT == 64) dma_launch<3, 1, 1, 1, 64, 8, 32, 8>(a, st);
+        else if (TH == 16) dma_launch<3, 1, 1, 1, 32, 16, 32, 8>(a, st);
+        else dma_launch<3, 1, 1, 1, 32, 8, 32, 8>(a, st);
     } else if (s.KS == 3) {
-        if (MT == 64) dma_launch<3, 2, 64, 8, 32, 4>(a, st);
-        else dma_launch<3, 2, 32, 8, 32, 4>(a, st);
+        if (MT == 64) dma_launch<3, 2, 1, 1, 64, 8, 32, 4>(a, st);
+        else dma_launch<3, 2, 1, 1, 32, 8, 32, 4>(a, st);
     } else {
-        if (MT == 128) dma_launch<1, 1, 128, 8, 32, 16>(a, st);
-        else if (MT == 64) dma_launch<1, 1, 64, 8, 32, 16>(a, st);
-        else if (TH == 16) dma_launch<1, 1, 32, 16, 32, 16>(a, st);
-        else dma_launch<1, 1, 32, 8, 32, 16>(a, st);
+        if (MT == 128) dma_launch<1, 1, 1, 1, 128, 8, 32, 16>(a, st);
+        else if (MT == 64) dma_launch<1, 1, 1, 1, 64, 8, 32, 16>(a, st);
+        else if (TH == 16) dma_launch<1, 1, 1, 1, 32, 16, 32, 16>(a, st);
+        else dma_launch<1, 1, 1, 1, 32, 8, 32, 16>(a, st);
     }
 }
 

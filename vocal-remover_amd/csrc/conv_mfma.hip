@@ -320,14 +320,17 @@ static TileChoice pick_tile(const ConvArgs& a, const ConvShape& s) {
 }
 
 bool ws_pick(const ConvArgs& a, const ConvShape& s, int* MT_out, int* TH_out);
-bool dma_pick(const ConvArgs& a, const ConvShape& s, int* MT_out, int* TH_out);
-void dma_launch_conv(const ConvArgs& a, const ConvShape& s, int MT, int TH, hipStream_t st);
+struct DmaTile { int MT, TH, TW; };
+bool dma_pick(const ConvArgs& a, const ConvShape& s, DmaTile* t);
+void dma_fill_tiling(ConvArgs& a, const DmaTile& t);
+void dma_launch_conv(const ConvArgs& a, const ConvShape& s, const DmaTile& t, hipStream_t st);
 void ws_fill_tiling(ConvArgs& a, int MT, int TH);
 void ws_launch_conv(const ConvArgs& a, const ConvShape& s, int MT, int TH, hipStream_t st);
 
 void conv_fill_tiling(ConvArgs& a, const ConvShape& s) {
     int wmt, wth;
-    if (dma_pick(a, s, &wmt, &wth)) { ws_fill_tiling(a, wmt, wth); return; }
+    DmaTile dt;
+    if (dma_pick(a, s, &dt)) { dma_fill_tiling(a, dt); return; }
     if (ws_pick(a, s, &wmt, &wth)) { ws_fill_tiling(a, wmt, wth); return; }
     TileChoice t = pick_tile(a, s);
     a.tiles_w = (a.Wout + t.TW - 1) / t.TW;
@@ -383,10 +386,11 @@ double launch_conv(const ConvArgs& a_in, const ConvShape& s, hipStream_t st) {
     a.dbg = dbg;
     {
         int wmt, wth;
-        if (dma_pick(a, s, &wmt, &wth)) {
+        DmaTile dt;
+        if (dma_pick(a, s, &dt)) {
             VR_CHECK(a.nsrc >= 1 && a.nsrc <= 3, -2, "conv takes 1..3 sources");
-            ws_fill_tiling(a, wmt, wth);
-            dma_launch_conv(a, s, wmt, wth, st);
+            dma_fill_tiling(a, dt);
+            dma_launch_conv(a, s, dt, st);
             return 2.0 * a.N * (double)a.Hout * a.Wout * (double)a.Cout * a.Cin * s.KS * s.KS;
         }
         if (ws_pick(a, s, &wmt, &wth)) {

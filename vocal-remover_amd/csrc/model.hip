@@ -458,7 +458,7 @@ Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs, int N, const T
     // Eval: the folded BatchNorm + activation go into the conv's epilogue, so the stored tensor is the
     // final activation and its consumers load it with no arithmetic (conv_dma.hip).  Training keeps
     // the raw tensor + pending affine: the batch statistics only exist after the whole conv has run.
-    const bool fuse_epi = !training && L.bn != nullptr && !batch_as_h;   // (the LSTM dense layer applies its own)
+    const bool fuse_epi = !training && L.bn != nullptr;
     if (fuse_epi) { a.epi = L.bn->affine; a.epi_slope = L.slope; }
     Tensor o;
     if (batch_as_h) {
@@ -571,7 +571,7 @@ Tensor Model::run_lstm(LSTMMod& M, const Tensor& h) {
     // BatchNorm1d + ReLU (lib/layers.py:120-121).  Eval: in place.  Train: the raw values are what the
     // BatchNorm backward needs, so the activated copy goes to its own buffer and shares lin's gradient.
     float* act = training ? ws.allocf((size_t)N * nb * nf) : lin.p;
-    if (!dry) launch_rows_affine_relu(lin.p, act, M.dense.bn->affine, N, nb, nf, stream);
+    if (!dry && training) launch_rows_affine_relu(lin.p, act, M.dense.bn->affine, N, nb, nf, stream);   // eval: fused into the conv epilogue
     Tensor o;                                                                   // [N,1,nb,nf], already activated
     o.p = act; o.g = lin.g; o.N = N; o.C = 1; o.H = nb; o.W = nf;
     o.sN = (long long)nb * nf; o.sC = (long long)nb * nf; o.sH = nf; o.slope = 1.f;
@@ -929,13 +929,20 @@ void Model::separate_api(const float* spec, bool on_dev, int T, int tta, int bat
         launch_stats_init(stats, stream);
         launch_mag_pad(reinterpret_cast<const float2*>(sd), bins, T, mag, Wpad, pl, stats, stream);
         launch_coef_affine(stats, tta ? 1 : 0, in_aff, stream);
+        {   // X_mag / coef once, so that the first conv of every BaseNet reads a plain tensor (LDS-DMA path)
+            Tensor m;
+            m.p = mag; m.N = 1; m.C = 2; m.H = bins; m.W = Wpad;
+            m.sH = Wpad; m.sC = (long long)bins * Wpad; m.sN = 2 * m.sC;
+            m.aff0 = in_aff; m.slope = 1.f;
+            launch_materialize(m, mag, stream);          // element-wise, in place
+        }
         for (int i = 0; i < patches; i += bs) {
             const int nb = std::min(bs, patches - i);
             ws.reset();
             Tensor x;
             x.p = mag + (size_t)i * roi; x.N = nb; x.C = 2; x.H = max_bin; x.W = cropsize;
             x.sN = roi; x.sC = (long long)bins * Wpad; x.sH = Wpad;
-            x.aff0 = in_aff; x.slope = 1.f;
+            x.slope = 1.f;
             Tensor f3 = run_net(x);
             HeadDst d{};
             d.p = mask[ps] + (size_t)i * roi; d.dN = roi; d.dC = (long long)bins * Wm[ps]; d.dH = Wm[ps];

@@ -238,37 +238,55 @@ __global__ void materialize_kernel(Tensor x, float* out, long long total) {
 // into a dense [N][C][2H][2W] buffer: eval mode materialises the decoder's upsampled input once so
 // that the consuming conv can take the LDS-DMA path (plain input, no arithmetic in the loader).
 // Same arithmetic (tap weights and summation order) as the fused loader in conv_stage.h.
-__global__ void upsample2x_kernel(Tensor x, float* out, float rh, float rw, long long total) {
+template <int V>      // V consecutive output columns per thread (4: one 16-B store; 2: odd source widths)
+__global__ __launch_bounds__(256) void upsample2x_kernel(Tensor x, float* __restrict__ out, float rh, float rw,
+                                                         long long total4) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total) return;
-    const int W2 = 2 * x.W, H2 = 2 * x.H;
-    const int wi = (int)(gid % W2);
-    long long t = gid / W2;
+    if (gid >= total4) return;
+    const int W2 = 2 * x.W, H2 = 2 * x.H, Q = W2 / V;
+    const int wq = (int)(gid % Q);
+    long long t = gid / Q;
     const int hi = (int)(t % H2); t /= H2;
     const int c = (int)(t % x.C);
     const int n = (int)(t / x.C);
-    const float h1r = rh * (float)hi, w1r = rw * (float)wi;
-    const int h1 = (int)h1r, w1 = (int)w1r;
-    const int h1p = (h1 < x.H - 1) ? 1 : 0, w1p = (w1 < x.W - 1) ? 1 : 0;
-    const float h1l = h1r - (float)h1, w1l = w1r - (float)w1;
-    const float h0l = 1.f - h1l, w0l = 1.f - w1l;
-    const float* q0 = x.p + (long long)n * x.sN + (long long)c * x.sC + (long long)h1 * x.sH + w1;
-    const float* q1 = q0 + (long long)h1p * x.sH;
+    const float h1r = rh * (float)hi;
+    const int h1 = (int)h1r;
+    const int h1p = (h1 < x.H - 1) ? 1 : 0;
+    const float h1l = h1r - (float)h1, h0l = 1.f - h1l;
+    const float* r0 = x.p + (long long)n * x.sN + (long long)c * x.sC + (long long)h1 * x.sH;
+    const float* r1 = r0 + (long long)h1p * x.sH;
     float sc0, sh0, sc1, sh1;
     load_aff(x, h1, c, sc0, sh0);
     load_aff(x, h1 + h1p, c, sc1, sh1);
-    const float v00 = act1(fmaf(q0[0], sc0, sh0), x.slope);
-    const float v01 = act1(fmaf(q0[w1p], sc0, sh0), x.slope);
-    const float v10 = act1(fmaf(q1[0], sc1, sh1), x.slope);
-    const float v11 = act1(fmaf(q1[w1p], sc1, sh1), x.slope);
-    out[gid] = h0l * (w0l * v00 + w1l * v01) + h1l * (w0l * v10 + w1l * v11);
+    float o[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int wi = wq * V + j;
+        const float w1r = rw * (float)wi;
+        const int w1 = (int)w1r;
+        const int w1p = (w1 < x.W - 1) ? 1 : 0;
+        const float w1l = w1r - (float)w1, w0l = 1.f - w1l;
+        const float v00 = act1(fmaf(r0[w1], sc0, sh0), x.slope);
+        const float v01 = act1(fmaf(r0[w1 + w1p], sc0, sh0), x.slope);
+        const float v10 = act1(fmaf(r1[w1], sc1, sh1), x.slope);
+        const float v11 = act1(fmaf(r1[w1 + w1p], sc1, sh1), x.slope);
+        o[j] = h0l * (w0l * v00 + w1l * v01) + h1l * (w0l * v10 + w1l * v11);
+    }
+    if constexpr (V == 4) reinterpret_cast<float4*>(out)[gid] = make_float4(o[0], o[1], o[2], o[3]);
+    else reinterpret_cast<float2*>(out)[gid] = make_float2(o[0], o[1]);
 }
 
 void launch_upsample2x(const Tensor& x, float* out, hipStream_t st) {
-    const long long total = (long long)x.N * x.C * x.H * x.W * 4;
     const float rh = (x.H > 0) ? (float)(x.H - 1) / (float)(2 * x.H - 1) : 0.f;
     const float rw = (x.W > 0) ? (float)(x.W - 1) / (float)(2 * x.W - 1) : 0.f;
-    hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, out, rh, rw, total);
+    const long long total = (long long)x.N * x.C * x.H * x.W * 4;
+    if ((x.W & 1) == 0) {
+        const long long tv = total / 4;
+        hipLaunchKernelGGL(upsample2x_kernel<4>, dim3((unsigned)((tv + 255) / 256)), dim3(256), 0, st, x, out, rh, rw, tv);
+    } else {
+        const long long tv = total / 2;
+        hipLaunchKernelGGL(upsample2x_kernel<2>, dim3((unsigned)((tv + 255) / 256)), dim3(256), 0, st, x, out, rh, rw, tv);
+    }
     VR_HIP(hipGetLastError());
 }
 
