@@ -56,10 +56,10 @@ struct DmaCfg {
 
 __device__ __forceinline__ i32x4 make_rsrc(const float* base, unsigned bytes) {
     const unsigned long long b = (unsigned long long)base;
-    i32x4 r;
-    r[0] = (int)(unsigned)(b & 0xffffffffull);
-    r[1] = (int)(unsigned)((b >> 32) & 0xffffull);
-    r[2] = (int)bytes;
+    i32x4 r;      // readfirstlane: the descriptor must live in SGPRs; its inputs are wave-uniform by construction
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(b & 0xffffffffull));
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((b >> 32) & 0xffffull));
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
     r[3] = 0x00020000;
     return r;
 }
@@ -251,6 +251,42 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
     }
 
     // ---------------- epilogue: bias, (eval) BatchNorm+activation, up to three destination segments -----
+    if (a.d1 >= a.CoutPad) {
+        // one destination (every forward conv): pixel offsets once per thread, one row pointer per cout
+        long long offn[WN];
+        bool okn[WN];
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) {
+            const int pix = (wave * WN + ni) * 32 + l31;
+            const int ho = h0 + pix / TW, wo = w0 + pix % TW;
+            okn[ni] = ho < a.Hout && wo < a.Wout && a.dst[0].p != nullptr;
+            offn[ni] = (long long)ho * a.dst[0].sH + wo;
+        }
+        float* dbase = a.dst[0].p + (long long)n * a.dst[0].sN;
+        const int dacc = a.dst[0].accumulate;
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                const int cc = co < a.Cout ? co : a.Cout - 1;
+                const float b = a.bias ? a.bias[cc] : 0.f;
+                float esc = 1.f, esh = 0.f, eslope = 1.f;
+                if (a.epi) { esc = a.epi[2 * cc]; esh = a.epi[2 * cc + 1]; eslope = a.epi_slope; }
+                float* qrow = dbase + (long long)co * a.dst[0].sC;
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni) {
+                    const float v = acc[mi][ni][r] + b;
+                    acc[mi][ni][r] = v;
+                    if (co < a.Cout && okn[ni]) {
+                        float* q = qrow + offn[ni];
+                        const float y = act_apply(fmaf(v, esc, esh), eslope);
+                        *q = dacc ? *q + y : y;
+                    }
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int mi = 0; mi < WM; ++mi) {
 #pragma unroll
@@ -280,6 +316,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
                 }
             }
         }
+    }
     }
     // ---------------- BatchNorm partial statistics (training) -------------------------------------------------
     if (a.part) {
@@ -398,17 +435,18 @@ void dma_fill_tiling(ConvArgs& a, const DmaTile& t) {
 void dma_launch_conv(const ConvArgs& a, const ConvShape& s, const DmaTile& t, hipStream_t st) {
     const int MT = t.MT, TH = t.TH;
     if (t.TW == 16) {
-        if (s.KS == 1) dma_launch<1, 1, 1, 1, 32, 16, 16, 16>(a, st);
+        if (s.KS == 1) dma_launch<1, 1, 1, 1, 32, 16, 16, 32>(a, st);
         else if (s.stride == 2) dma_launch<3, 2, 1, 1, 32, 16, 16, 4>(a, st);
         else if (s.dil_h == 1) dma_launch<3, 1, 1, 1, 32, 16, 16, 8>(a, st);
         else if (s.dil_h == 4) dma_launch<3, 1, 4, 2, 32, 16, 16, 4>(a, st);
         else if (s.dil_h == 8) dma_launch<3, 1, 8, 4, 32, 16, 16, 4>(a, st);
         else dma_launch<3, 1, 12, 6, 32, 16, 16, 4>(a, st);
     } else if (s.KS == 3 && s.stride == 1) {
+        static const int ck4 = getenv("VR_DMA_CK4") ? atoi(getenv("VR_DMA_CK4")) : 7;   // tuning experiment
         if (MT == 128) dma_launch<3, 1, 1, 1, 128, 8, 32, 4>(a, st);
-        else if (MT == 64) dma_launch<3, 1, 1, 1, 64, 8, 32, 8>(a, st);
-        else if (TH == 16) dma_launch<3, 1, 1, 1, 32, 16, 32, 8>(a, st);
-        else dma_launch<3, 1, 1, 1, 32, 8, 32, 8>(a, st);
+        else if (MT == 64) { if (ck4 & 1) dma_launch<3, 1, 1, 1, 64, 8, 32, 4>(a, st); else dma_launch<3, 1, 1, 1, 64, 8, 32, 8>(a, st); }
+        else if (TH == 16) { if (ck4 & 2) dma_launch<3, 1, 1, 1, 32, 16, 32, 4>(a, st); else dma_launch<3, 1, 1, 1, 32, 16, 32, 8>(a, st); }
+        else { if (ck4 & 4) dma_launch<3, 1, 1, 1, 32, 8, 32, 4>(a, st); else dma_launch<3, 1, 1, 1, 32, 8, 32, 8>(a, st); }
     } else if (s.KS == 3) {
         if (MT == 64) dma_launch<3, 2, 1, 1, 64, 8, 32, 4>(a, st);
         else dma_launch<3, 2, 1, 1, 32, 8, 32, 4>(a, st);

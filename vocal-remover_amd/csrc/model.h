@@ -88,7 +88,7 @@ struct BaseNetL {
 void merge_artifacts_weight(const std::vector<float>& fmin, std::vector<float>& weight, float thres, int min_range,
                             int fade);
 
-struct ProfileEntry { hipEvent_t e0, e1; double flops; int kind; };
+struct ProfileEntry { hipEvent_t e0, e1; double flops; int kind; std::string tag; };
 
 class Model {
 public:
@@ -137,6 +137,13 @@ public:
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;          // eval mode: the high-band chain runs here
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // eval mode, second lane: the crops of a batch are independent, so separate() runs the two halves
+    // of the batch as two concurrent chains (own streams, own workspace); the tail of one chain's
+    // kernels and its memory-bound kernels (upsample, LSTM, copies) overlap the other chain's convs.
+    hipStream_t stream_b = nullptr, side_b = nullptr;
+    hipEvent_t evb_fork = nullptr, evb_join = nullptr, evb_start = nullptr, evb_done = nullptr;
+    Arena ws_b;
+    void swap_lane();
 
 private:
     // arenas

@@ -130,6 +130,14 @@ Model::Model(int device_, int n_fft_, int hop_, int nout_, int nout_lstm_)
         VR_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
         VR_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         VR_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        if (!getenv("VR_NO_SPLIT_BATCH")) {
+            VR_HIP(hipStreamCreateWithFlags(&stream_b, hipStreamNonBlocking));
+            VR_HIP(hipStreamCreateWithFlags(&side_b, hipStreamNonBlocking));
+            VR_HIP(hipEventCreateWithFlags(&evb_fork, hipEventDisableTiming));
+            VR_HIP(hipEventCreateWithFlags(&evb_join, hipEventDisableTiming));
+            VR_HIP(hipEventCreateWithFlags(&evb_start, hipEventDisableTiming));
+            VR_HIP(hipEventCreateWithFlags(&evb_done, hipEventDisableTiming));
+        }
     }
     const int nin = 2;
     const int nin_lstm = max_bin / 2;
@@ -225,6 +233,12 @@ Model::~Model() {
     hipFree(ws.base); hipFree(io.base); hipFree(gs.base);
     hipFree(g_arena); hipFree(m_arena); hipFree(v_arena); hipFree(wt_arena); hipFree(d_flip); hipFree(dropout_buf);
     hipFree(plan.twiddle); hipFree(plan.window);
+    if (stream_b) {
+        hipStreamSynchronize(stream_b); hipStreamSynchronize(side_b);
+        hipStreamDestroy(stream_b); hipStreamDestroy(side_b);
+        hipEventDestroy(evb_fork); hipEventDestroy(evb_join); hipEventDestroy(evb_start); hipEventDestroy(evb_done);
+        hipFree(ws_b.base);
+    }
     if (side_stream) { hipStreamSynchronize(side_stream); hipStreamDestroy(side_stream); hipEventDestroy(ev_fork); hipEventDestroy(ev_join); }
     if (stream) hipStreamDestroy(stream);
 }
@@ -318,6 +332,16 @@ void Model::ensure_ws(size_t bytes) {
     ws.cap = want;
 }
 
+// Exchange lane A (stream, side_stream, ws) with lane B: run_net() and the launch helpers only know the
+// member names, so the second half-batch is enqueued by swapping, running, swapping back.
+void Model::swap_lane() {
+    std::swap(stream, stream_b);
+    std::swap(side_stream, side_b);
+    std::swap(ev_fork, evb_fork);
+    std::swap(ev_join, evb_join);
+    std::swap(ws, ws_b);
+}
+
 void Model::ensure_io(size_t bytes) {
     if (bytes <= io.cap) return;
     VR_HIP(hipStreamSynchronize(stream));
@@ -356,6 +380,9 @@ void Model::profile_end(double* conv_ms, double* conv_flops, double* other_ms, i
         float ms = 0.f;
         VR_HIP(hipEventElapsedTime(&ms, e.e0, e.e1));
         if (e.kind == 0) { cm += ms; cf += e.flops; ++n; } else om += ms;
+        static const bool dump = getenv("VR_PROFILE_DUMP") != nullptr;       // per-launch table on stderr
+        if (dump) fprintf(stderr, "[vr-prof] %-44s %9.1f us %8.2f GFLOP %7.1f TFLOP/s\n", e.tag.c_str(), ms * 1e3,
+                          e.flops * 1e-9, ms > 0 ? e.flops / ms * 1e-9 : 0.0);
         hipEventDestroy(e.e0); hipEventDestroy(e.e1);
     }
     prof.clear();
@@ -491,6 +518,12 @@ Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs, int N, const T
     if (!dry) {
         const double flops = 2.0 * N * (double)(batch_as_h ? 1 : a.Hout) * a.Wout * (double)L.Cout * L.Cin * L.KS * L.KS;
         record_begin(0, flops);
+        if (profiling) {
+            char tag[160];
+            snprintf(tag, sizeof tag, "%s k%d s%d d%d ci%d co%d %dx%dx%d", L.name.c_str(), L.KS, L.stride, L.dh, L.Cin,
+                     L.Cout, a.N, a.Hout, a.Wout);
+            prof.back().tag = tag;
+        }
         launch_conv(a, shp, stream);
         record_end();
         if (stats) {
@@ -936,18 +969,41 @@ void Model::separate_api(const float* spec, bool on_dev, int T, int tta, int bat
             m.aff0 = in_aff; m.slope = 1.f;
             launch_materialize(m, mag, stream);          // element-wise, in place
         }
-        for (int i = 0; i < patches; i += bs) {
-            const int nb = std::min(bs, patches - i);
+        auto run_crops = [&](int first, int count) {
             ws.reset();
             Tensor x;
-            x.p = mag + (size_t)i * roi; x.N = nb; x.C = 2; x.H = max_bin; x.W = cropsize;
+            x.p = mag + (size_t)first * roi; x.N = count; x.C = 2; x.H = max_bin; x.W = cropsize;
             x.sN = roi; x.sC = (long long)bins * Wpad; x.sH = Wpad;
             x.slope = 1.f;
             Tensor f3 = run_net(x);
             HeadDst d{};
-            d.p = mask[ps] + (size_t)i * roi; d.dN = roi; d.dC = (long long)bins * Wm[ps]; d.dH = Wm[ps];
+            d.p = mask[ps] + (size_t)first * roi; d.dN = roi; d.dC = (long long)bins * Wm[ps]; d.dH = Wm[ps];
             d.w_lo = offset; d.w_hi = cropsize - offset; d.pad_rows = output_bin - max_bin;
             launch_head_sigmoid(f3, out_w->dev, d, stream);
+        };
+        for (int i = 0; i < patches; i += bs) {
+            const int nb = std::min(bs, patches - i);
+            const bool split = stream_b != nullptr && !profiling && nb >= 2;
+            if (!split) {
+                run_crops(i, nb);
+                continue;
+            }
+            const int na = (nb + 1) / 2;
+            if (ws_b.cap < ws.cap) {                     // lane B's workspace: same plan, same size
+                VR_HIP(hipDeviceSynchronize());
+                if (ws_b.base) VR_HIP(hipFree(ws_b.base));
+                ws_b.base = nullptr; ws_b.cap = 0;
+                VR_HIP(hipMalloc(reinterpret_cast<void**>(&ws_b.base), ws.cap));
+                ws_b.cap = ws.cap;
+            }
+            VR_HIP(hipEventRecord(evb_start, stream));   // `mag` is ready at this point of lane A's stream
+            VR_HIP(hipStreamWaitEvent(stream_b, evb_start, 0));
+            run_crops(i, na);
+            swap_lane();
+            try { run_crops(i + na, nb - na); } catch (...) { swap_lane(); throw; }
+            VR_HIP(hipEventRecord(evb_done, stream));
+            swap_lane();
+            VR_HIP(hipStreamWaitEvent(stream, evb_done, 0));
         }
     }
     const float* wgt = nullptr;
