@@ -19,10 +19,10 @@
 #include <cstdlib>
 
 #include "conv_stage.h"
+#include "lds_dma.h"
 
 namespace vr {
 
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 struct DmaTile { int MT, TH, TW; };
 
 template <int KS, int S, int DH, int DW, int MT, int TH, int TW, int CK>
@@ -53,28 +53,6 @@ struct DmaCfg {
     static_assert(CK % 4 == 0 && BUF % 4 == 0 && XS % 4 == 0 && CSX % 4 == 0, "16-B LDS slabs");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
-
-__device__ __forceinline__ i32x4 make_rsrc(const float* base, unsigned bytes) {
-    const unsigned long long b = (unsigned long long)base;
-    i32x4 r;      // readfirstlane: the descriptor must live in SGPRs; its inputs are wave-uniform by construction
-    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(b & 0xffffffffull));
-    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((b >> 32) & 0xffffull));
-    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
-    r[3] = 0x00020000;
-    return r;
-}
-
-// One 64-lane LDS-DMA: lane l copies 16 B from rsrc.base + voff[l] to LDS byte lds_base + 16*l.
-__device__ __forceinline__ void dma16(unsigned lds_base, unsigned voff, i32x4 rsrc) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                 :: "s"(lds_base), "v"(voff), "s"(rsrc) : "memory");
-}
-
-__device__ __forceinline__ void dma_wait_and_barrier() {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
 
 template <int KS, int S, int DH, int DW, int MT, int TH, int TW, int CK>
 __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {

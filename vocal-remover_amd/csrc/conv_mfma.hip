@@ -320,6 +320,9 @@ static TileChoice pick_tile(const ConvArgs& a, const ConvShape& s) {
 }
 
 bool ws_pick(const ConvArgs& a, const ConvShape& s, int* MT_out, int* TH_out);
+bool wino_pick(const ConvArgs& a, const ConvShape& s, int* MT_out);
+void wino_fill_tiling(ConvArgs& a, int MT);
+void wino_launch_conv(const ConvArgs& a, int MT, hipStream_t st);
 struct DmaTile { int MT, TH, TW; };
 bool dma_pick(const ConvArgs& a, const ConvShape& s, DmaTile* t);
 void dma_fill_tiling(ConvArgs& a, const DmaTile& t);
@@ -329,6 +332,8 @@ void ws_launch_conv(const ConvArgs& a, const ConvShape& s, int MT, int TH, hipSt
 
 void conv_fill_tiling(ConvArgs& a, const ConvShape& s) {
     int wmt, wth;
+    int wino_mt;
+    if (wino_pick(a, s, &wino_mt)) { wino_fill_tiling(a, wino_mt); return; }
     DmaTile dt;
     if (dma_pick(a, s, &dt)) { dma_fill_tiling(a, dt); return; }
     if (ws_pick(a, s, &wmt, &wth)) { ws_fill_tiling(a, wmt, wth); return; }
@@ -386,6 +391,12 @@ double launch_conv(const ConvArgs& a_in, const ConvShape& s, hipStream_t st) {
     a.dbg = dbg;
     {
         int wmt, wth;
+        int wino_mt;
+        if (a.nsrc >= 1 && a.nsrc <= 3 && wino_pick(a, s, &wino_mt)) {
+            wino_fill_tiling(a, wino_mt);
+            wino_launch_conv(a, wino_mt, st);
+            return 2.0 * a.N * (double)a.Hout * a.Wout * (double)a.Cout * a.Cin * s.KS * s.KS;
+        }
         DmaTile dt;
         if (dma_pick(a, s, &dt)) {
             VR_CHECK(a.nsrc >= 1 && a.nsrc <= 3, -2, "conv takes 1..3 sources");

@@ -1,0 +1,355 @@
+// Winograd F(2x2, 3x3) convolution for the stride-1 3x3 layers with plain inputs (lib/layers.py:12-20,
+// the layers that hold ~80 % of the network's multiply-adds).
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A       d: 4x4 input patch, g: 3x3 filter, Y: 2x2 outputs
+//
+// 16 multiplies per 2x2 outputs instead of 36: the MFMA work drops 2.25x, which is the only way past the
+// fp32 matrix-pipe roof the direct kernel (conv_dma.hip) already sits at on the big layers.  The 16
+// element-wise products become 16 independent GEMMs over the input channels,
+//   M_f[cout][tile] += U_f[cout][cin] * V_f[cin][tile],        f = 0..15,
+// run on v_mfma_f32_32x32x2_f32 exactly like the direct conv (cout = rows, 32 tiles = columns).
+//
+// Workgroup = 512 threads / 8 waves, output tile 8 x 32 pixels (= 64 Winograd tiles), MT couts,
+// input channels in chunks of 8:
+//   * raw input rows and the pre-transformed weights U (model.hip keeps G g G^T per layer) arrive by
+//     LDS-DMA (lds_dma.h); wave w fetches input channel w of the chunk and 1/8 of the weight slab;
+//   * wave w transforms ITS OWN channel (lane = tile; 16 LDS reads, 32 adds, 16 LDS writes) -- no
+//     cross-wave dependency between the DMA and the transform, so one barrier per chunk suffices;
+//   * wave w multiplies frequencies 2w and 2w+1 (accumulators 2 x MT/32 x 2 tiles of 32x32);
+//   * epilogue: the 16 frequencies of a (cout, tile) pair live in 8 different waves, so they meet in
+//     LDS (32 couts x 32 tiles per pass), A^T M A, bias / folded BatchNorm / activation, 8-byte stores.
+// fp32 throughout; the transforms only add and halve, the measured deviation from the direct kernel
+// is ~1e-6 relative (tests/test_gpu_parity.py::test_conv_winograd_vs_direct).
+#include <cstdlib>
+
+#include "conv_stage.h"
+#include "lds_dma.h"
+
+namespace vr {
+
+template <int MT>
+struct WinoCfg {
+    static constexpr int TH = 8, TW = 32, CK = 8, NT = 64;           // pixels, channels per chunk, Winograd tiles
+    static constexpr int TH_in = TH + 2, XS0 = 3, TWq = 40, CSX = TH_in * TWq;
+    static constexpr int WM = MT / 32;
+    static constexpr int XS = CK * CSX;                                // raw input rows (single buffer)
+    static constexpr int WS = 16 * CK * MT;                            // U slab   [f][cl][m]
+    static constexpr int VS = 16 * CK * NT;                            // V slab   [f][cl][tile]
+    static constexpr int LDS_FLOATS = XS + 2 * WS + 2 * VS;
+    static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+    static constexpr int NPIECE = CSX / 4, NPASS = (NPIECE + 63) / 64;
+    static constexpr int NWP = WS / 4, NWPASS = NWP / 512;             // 16-B weight pieces per wave-pass
+    static constexpr int MP = 33;                                      // epilogue exchange pitch
+    static_assert(NWP % 512 == 0, "weight slab splits evenly over 8 waves");
+    static_assert(16 * 32 * MP <= LDS_FLOATS && LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+template <int MT>
+__global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
+    using Cfg = WinoCfg<MT>;
+    constexpr int TH = Cfg::TH, TW = Cfg::TW, CK = Cfg::CK, NT = Cfg::NT, TWq = Cfg::TWq, CSX = Cfg::CSX, XS0 = Cfg::XS0,
+                  WM = Cfg::WM, NPIECE = Cfg::NPIECE, NPASS = Cfg::NPASS, NWPASS = Cfg::NWPASS, MP = Cfg::MP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xraw = smem;
+    float* WsB = smem + Cfg::XS;                       // two U buffers
+    float* VsB = WsB + 2 * Cfg::WS;                    // two V buffers
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int rr = id >> 3;
+    const int ct = rr % a.nct;
+    const int pt = (rr / a.nct) * 8 + xcd;
+    if (pt >= a.npt) return;
+    const int tiles_per_img = a.tiles_h * a.tiles_w;
+    const int n = pt / tiles_per_img;
+    const int trem = pt - n * tiles_per_img;
+    const int h0 = (trem / a.tiles_w) * TH;
+    const int w0 = (trem % a.tiles_w) * TW;
+    const int co0 = ct * MT;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // 0..7
+    const int hbase = h0 - 1, wal0 = w0 - 1 - XS0;
+    const int nchunk = (a.Cin + CK - 1) / CK;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+
+    // per-lane source coordinates of this wave's input pieces (see conv_dma.hip)
+    unsigned hrow[NPASS], wcol4[NPASS];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int q = p * 64 + lane;
+        const int hh = q / (TWq / 4), j = q % (TWq / 4);
+        const int hi = hbase + hh, wi = wal0 + 4 * j;
+        const bool ok = q < NPIECE && hi >= 0 && hi < a.Hin && wi >= 0 && wi + 3 < a.Win;
+        hrow[p] = ok ? (unsigned)hi : 0u;
+        wcol4[p] = ok ? (unsigned)(wi * 4) : 0x80000000u;
+    }
+    // weight pieces: LDS order [f][cl][m], source U[(cl*16+f)*CoutPad + m]
+    unsigned woff[NWPASS];
+#pragma unroll
+    for (int i = 0; i < NWPASS; ++i) {
+        const int q = (wave + 8 * i) * 64 + lane;
+        const int m4 = q % (MT / 4), t2 = q / (MT / 4);
+        const int cl = t2 % CK, f = t2 / CK;
+        woff[i] = (unsigned)(((cl * 16 + f) * a.CoutPad + m4 * 4) * 4);
+    }
+
+    auto issue_chunk = [&](int k) {
+        const int c0 = k * CK;
+        const unsigned ws_b = lds0 + (unsigned)((Cfg::XS + (k & 1) * Cfg::WS) * 4);
+        {
+            const float* wb = a.wino + (long long)c0 * 16 * a.CoutPad + co0;
+            const i32x4 wr = make_rsrc(wb, (unsigned)(((long long)(a.Cin - c0) * 16 * a.CoutPad - co0) * 4));
+#pragma unroll
+            for (int i = 0; i < NWPASS; ++i) dma16(ws_b + (wave + 8 * i) * 1024, woff[i], wr);
+        }
+        const int cl = wave;                               // this wave's input channel of the chunk
+        const int ci = c0 + cl;
+        if (ci >= a.Cin) {
+            float* z = Xraw + cl * CSX;
+            for (int e = lane; e < CSX; e += 64) z[e] = 0.f;
+            return;
+        }
+        const int si = (ci >= a.c1) + (ci >= a.c2);
+        const int clc = ci - (si == 0 ? 0 : (si == 1 ? a.c1 : a.c2));
+        const float* sp = si == 0 ? a.src[0].p : (si == 1 ? a.src[1].p : a.src[2].p);
+        const long long sN = si == 0 ? a.src[0].sN : (si == 1 ? a.src[1].sN : a.src[2].sN);
+        const long long sC = si == 0 ? a.src[0].sC : (si == 1 ? a.src[1].sC : a.src[2].sC);
+        const unsigned sH4 = (unsigned)(si == 0 ? a.src[0].sH : (si == 1 ? a.src[1].sH : a.src[2].sH)) * 4u;
+        const i32x4 xr = make_rsrc(sp + (long long)n * sN + (long long)clc * sC, 0x7FFFFFF0u);
+        const unsigned cb = lds0 + (unsigned)(cl * CSX * 4);
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const unsigned vo = hrow[p] * sH4 + wcol4[p];
+            if ((p + 1) * 64 <= NPIECE) dma16(cb + p * 1024, vo, xr);
+            else if (p * 64 + lane < NPIECE) dma16(cb + p * 1024, vo, xr);
+        }
+    };
+
+    // input transform of this wave's channel: lane = Winograd tile (ti = lane >> 4, tj = lane & 15)
+    const int xpo = wave * CSX + (2 * (lane >> 4)) * TWq + 2 * (lane & 15) + XS0;
+    auto transform = [&](int k) {
+        const float* xp = Xraw + xpo;
+        float* V = VsB + (k & 1) * Cfg::VS + wave * NT + lane;      // + f * CK * NT
+        float t[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float d0 = xp[c], d1 = xp[TWq + c], d2 = xp[2 * TWq + c], d3 = xp[3 * TWq + c];
+            t[0][c] = d0 - d2;
+            t[1][c] = d1 + d2;
+            t[2][c] = d2 - d1;
+            t[3][c] = d1 - d3;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            V[(r * 4 + 0) * CK * NT] = t[r][0] - t[r][2];
+            V[(r * 4 + 1) * CK * NT] = t[r][1] + t[r][2];
+            V[(r * 4 + 2) * CK * NT] = t[r][2] - t[r][1];
+            V[(r * 4 + 3) * CK * NT] = t[r][1] - t[r][3];
+        }
+    };
+
+    const int khalf = lane >> 5, l31 = lane & 31;
+    f32x16 acc[2][WM][2];
+#pragma unroll
+    for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[fi][mi][ni][r] = 0.f;
+
+    issue_chunk(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    transform(0);
+    lds_barrier();
+
+    const int aoff = khalf * MT + l31;          // + (f*CK + 2kk)*MT + mi*32
+    const int boff = khalf * NT + l31;          // + (f*CK + 2kk)*NT + ni*32
+    for (int k = 0; k < nchunk; ++k) {
+        if (k + 1 < nchunk) issue_chunk(k + 1);
+        const float* Ws = WsB + (k & 1) * Cfg::WS + (2 * wave) * CK * MT + aoff;
+        const float* Vs = VsB + (k & 1) * Cfg::VS + (2 * wave) * CK * NT + boff;
+        {
+            // 8 k-steps (2 frequencies x 4 channel pairs), operands of step s+1 read before the MFMAs of step s
+            float av[WM], bv[2];
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi) av[mi] = Ws[mi * 32];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) bv[ni] = Vs[ni * 32];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                float avn[WM], bvn[2];
+                if (s + 1 < 8) {
+                    const int fi = (s + 1) >> 2, kk = (s + 1) & 3;
+#pragma unroll
+                    for (int mi = 0; mi < WM; ++mi) avn[mi] = Ws[(fi * CK + 2 * kk) * MT + mi * 32];
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) bvn[ni] = Vs[(fi * CK + 2 * kk) * NT + ni * 32];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[s >> 2][mi][ni] =
+                            __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[s >> 2][mi][ni], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + 1 < 8) {
+#pragma unroll
+                    for (int mi = 0; mi < WM; ++mi) av[mi] = avn[mi];
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) bv[ni] = bvn[ni];
+                }
+            }
+        }
+        if (k + 1 < nchunk) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's channel of chunk k+1 has landed
+            transform(k + 1);
+        }
+        lds_barrier();
+    }
+
+    // ---------------- epilogue: gather the 16 frequencies per (cout, tile) through LDS, A^T M A ------------
+    float* Mx = smem;                                                  // [16][32][MP]
+    float* dbase = a.dst[0].p + (long long)n * a.dst[0].sN;
+    const int dacc = a.dst[0].accumulate;
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            if (mi + ni > 0) lds_barrier();                            // previous pass has been read
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int col = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    Mx[((2 * wave + fi) * 32 + col) * MP + l31] = acc[fi][mi][ni][r];
+                }
+            lds_barrier();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int p = tid + 512 * j;
+                const int col = p >> 5, tl = p & 31;
+                float m[16];
+#pragma unroll
+                for (int f = 0; f < 16; ++f) m[f] = Mx[(f * 32 + col) * MP + tl];
+                float s0[4], s1[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    s0[c] = m[c] + m[4 + c] + m[8 + c];
+                    s1[c] = m[4 + c] - m[8 + c] - m[12 + c];
+                }
+                float y[2][2];
+                y[0][0] = s0[0] + s0[1] + s0[2];
+                y[0][1] = s0[1] - s0[2] - s0[3];
+                y[1][0] = s1[0] + s1[1] + s1[2];
+                y[1][1] = s1[1] - s1[2] - s1[3];
+                const int co = co0 + mi * 32 + col;
+                const int T = ni * 32 + tl;
+                const int ho = h0 + 2 * (T >> 4), wo = w0 + 2 * (T & 15);
+                if (co < a.Cout && a.dst[0].p) {
+                    const float b = a.bias ? a.bias[co] : 0.f;
+                    float esc = 1.f, esh = 0.f, eslope = 1.f;
+                    if (a.epi) { esc = a.epi[2 * co]; esh = a.epi[2 * co + 1]; eslope = a.epi_slope; }
+#pragma unroll
+                    for (int dr = 0; dr < 2; ++dr) {
+                        if (ho + dr >= a.Hout) continue;
+                        float* q = dbase + (long long)co * a.dst[0].sC + (long long)(ho + dr) * a.dst[0].sH + wo;
+#pragma unroll
+                        for (int dc = 0; dc < 2; ++dc) {
+                            if (wo + dc >= a.Wout) continue;
+                            const float v = act_apply(fmaf(y[dr][dc] + b, esc, esh), eslope);
+                            q[dc] = dacc ? q[dc] + v : v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// U = G g G^T per (cin, cout):  w [Cin][9][CoutPad]  ->  u [Cin][16][CoutPad]
+__global__ void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int Cin, int CoutPad) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)Cin * CoutPad) return;
+    const int co = (int)(gid % CoutPad);
+    const int ci = (int)(gid / CoutPad);
+    float g[3][3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) g[i / 3][i % 3] = w[((long long)ci * 9 + i) * CoutPad + co];
+    float t[4][3];                                   // G g
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        t[0][c] = g[0][c];
+        t[1][c] = 0.5f * (g[0][c] + g[1][c] + g[2][c]);
+        t[2][c] = 0.5f * (g[0][c] - g[1][c] + g[2][c]);
+        t[3][c] = g[2][c];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                    // (G g) G^T
+        float* o = u + ((long long)ci * 16 + r * 4) * CoutPad + co;
+        o[0] = t[r][0];
+        o[(long long)CoutPad] = 0.5f * (t[r][0] + t[r][1] + t[r][2]);
+        o[2LL * CoutPad] = 0.5f * (t[r][0] - t[r][1] + t[r][2]);
+        o[3LL * CoutPad] = t[r][2];
+    }
+}
+
+void launch_wino_weights(const float* w, float* u, int Cin, int CoutPad, hipStream_t st) {
+    const long long n = (long long)Cin * CoutPad;
+    hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, u, Cin, CoutPad);
+    VR_HIP(hipGetLastError());
+}
+
+template <int MT>
+static void wino_launch(const ConvArgs& a, hipStream_t st) {
+    using Cfg = WinoCfg<MT>;
+    auto kern = conv_wino_kernel<MT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   Cfg::LDS_BYTES));
+        attr_set = true;
+    }
+    const int groups = (a.npt + 7) / 8;
+    const int grid = groups * 8 * a.nct;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), Cfg::LDS_BYTES, st, a);
+    VR_HIP(hipGetLastError());
+}
+
+// True when the launch can take the Winograd kernel (forward 3x3 stride-1, plain inputs, one destination,
+// no BatchNorm statistics wanted, transformed weights available).
+bool wino_pick(const ConvArgs& a, const ConvShape& s, int* MT_out) {
+    static const int enabled = getenv("VR_CONV_WINO") ? atoi(getenv("VR_CONV_WINO")) : 1;
+    if (!enabled || !a.wino || a.part) return false;
+    if (!(s.KS == 3 && s.stride == 1 && s.dil_h == 1 && s.dil_w == 1)) return false;
+    if (a.pad_h != 1 || a.pad_w != 1 || a.Wout < 32 || (a.Win & 3)) return false;
+    if (a.d1 < a.CoutPad) return false;
+    for (int i = 0; i < a.nsrc; ++i) {
+        const ConvSrc& c = a.src[i];
+        if (c.aff0 || c.aff1 || c.post || c.up || c.zins || c.slope != 1.f || c.W != a.Win) return false;
+        if ((long long)c.H * (c.sH > 0 ? c.sH : 1) * 4 >= 0x7FFFFFF0LL) return false;
+    }
+    if ((long long)a.Cin * 16 * a.CoutPad * 4 >= 0x7FFFFFF0LL) return false;
+    const long long tiles = (long long)a.N * ((a.Hout + 7) / 8) * ((a.Wout + 31) / 32);
+    int MT = (a.CoutPad % 64 == 0) ? 64 : 32;
+    if (MT == 64 && tiles * (a.CoutPad / 64) < 384) MT = 32;
+    *MT_out = MT;
+    return true;
+}
+
+void wino_fill_tiling(ConvArgs& a, int MT) {
+    a.tiles_w = (a.Wout + 31) / 32;
+    a.tiles_h = (a.Hout + 7) / 8;
+    a.npt = a.N * a.tiles_h * a.tiles_w;
+    a.nct = a.CoutPad / MT;
+}
+
+void wino_launch_conv(const ConvArgs& a, int MT, hipStream_t st) {
+    if (MT == 64) wino_launch<64>(a, st);
+    else wino_launch<32>(a, st);
+}
+
+}  // namespace vr

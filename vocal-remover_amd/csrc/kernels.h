@@ -43,6 +43,7 @@ void launch_add(const float* a, const float* b, float* out, int n, hipStream_t s
 
 // dense post-activation copy of a Tensor (debug taps / tests)
 void launch_materialize(const Tensor& x, float* out, hipStream_t st);
+void launch_wino_weights(const float* w, float* u, int Cin, int CoutPad, hipStream_t st);   // U = G g G^T
 void launch_upsample2x(const Tensor& x, float* out, hipStream_t st);   // dense [N][C][2H][2W], activated
 
 // ---- lstm.hip -----------------------------------------------------------------------------------

@@ -61,6 +61,7 @@ struct Conv {
     Param* w = nullptr;
     BN* bn = nullptr;
     float slope = 0.f;              // activation after the BatchNorm
+    float* wino = nullptr;          // eval: Winograd-transformed weights [Cin][16][CoutPad] (3x3 stride-1 layers)
 };
 
 struct LSTMMod {
@@ -156,6 +157,8 @@ private:
 
     std::deque<BN> bns;
     std::vector<BN*> bn_list;
+    std::vector<Conv*> wino_list;                        // 3x3 stride-1 layers (conv_wino.hip)
+    float* wino_arena = nullptr;
     BNFoldDesc* d_fold = nullptr;
     bool affine_dirty = true;
     void fold_eval_affines();

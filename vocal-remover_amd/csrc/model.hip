@@ -58,6 +58,7 @@ void Model::build_cba(Conv& L, const std::string& prefix, int nin, int nout_, in
     L.KS = ks; L.stride = stride; L.pad_h = pad_h; L.pad_w = pad_w; L.dh = dh; L.dw = dw; L.slope = slope;
     L.w = add_param(prefix + ".conv.0.weight", {nout_, nin, ks, ks}, PK_CONV, true);
     L.bn = add_bn(prefix + ".conv.1", nout_, 0);
+    if (ks == 3 && stride == 1 && dh == 1 && dw == 1) wino_list.push_back(&L);
 }
 
 // nets.BaseNet (lib/nets.py:10-24)
@@ -230,7 +231,7 @@ Model::~Model() {
     hipSetDevice(device);
     if (stream) hipStreamSynchronize(stream);
     hipFree(p_arena); hipFree(b_arena); hipFree(d_fold);
-    hipFree(ws.base); hipFree(io.base); hipFree(gs.base);
+    hipFree(ws.base); hipFree(io.base); hipFree(gs.base); hipFree(wino_arena);
     hipFree(g_arena); hipFree(m_arena); hipFree(v_arena); hipFree(wt_arena); hipFree(d_flip); hipFree(dropout_buf);
     hipFree(plan.twiddle); hipFree(plan.window);
     if (stream_b) {
@@ -316,6 +317,15 @@ void Model::fold_eval_affines() {
     int maxC = 1;
     for (BN* b : bn_list) maxC = std::max(maxC, std::max(b->C, b->bcast));
     launch_bn_fold_eval(d_fold, (int)bn_list.size(), maxC, 1e-5f, stream);
+    // the weights may have changed too (set_param / Adam): refresh the Winograd-domain copies G g G^T
+    if (!wino_arena) {
+        size_t total = 0;
+        for (Conv* L : wino_list) total += (size_t)L->Cin * 16 * L->CoutPad;
+        VR_HIP(hipMalloc(reinterpret_cast<void**>(&wino_arena), total * sizeof(float)));
+        size_t off = 0;
+        for (Conv* L : wino_list) { L->wino = wino_arena + off; off += (size_t)L->Cin * 16 * L->CoutPad; }
+    }
+    for (Conv* L : wino_list) launch_wino_weights(L->w->dev, L->wino, L->Cin, L->CoutPad, stream);
     affine_dirty = false;
 }
 
@@ -487,6 +497,7 @@ Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs, int N, const T
     // the raw tensor + pending affine: the batch statistics only exist after the whole conv has run.
     const bool fuse_epi = !training && L.bn != nullptr;
     if (fuse_epi) { a.epi = L.bn->affine; a.epi_slope = L.slope; }
+    if (!training) a.wino = L.wino;
     Tensor o;
     if (batch_as_h) {
         o.N = N; o.C = L.Cout; o.H = 1; o.W = a.Wout;

@@ -87,6 +87,7 @@ struct ConvArgs {
     int nsrc, c1, c2;          // src0 = channels [0,c1), src1 = [c1,c2), src2 = [c2,Cin)
     int Cin;
     const float* w;            // [Cin][KS*KS][CoutPad]  (K-major, cout contiguous)
+    const float* wino;         // Winograd F(2x2,3x3) weights [Cin][16][CoutPad] (G g G^T), or null
     const float* bias;         // [Cout] or null
     int Cout, CoutPad;
     ConvDst dst[3];
