@@ -110,9 +110,12 @@ int vr_profile_begin(vr_handle h);
 int vr_profile_end(vr_handle h, double* conv_ms, double* conv_flops, int* conv_launches);
 
 /* ---- test hooks (tests/ only) ---------------------------------------------------------------- */
-/* One convolution through the MFMA kernel: x [N,Cin,H,W] (optionally x2-upsampled, optionally with
- * a pending per-channel affine [Cin][2] + activation slope), w OIHW, padding = dilation (3x3) or 0
- * (1x1).  stats_out [Cout][2] receives (sum, sumsq) of the output per channel when non-null.      */
+/* One convolution through the library's conv dispatcher: x [N,Cin,H,W], w OIHW, padding = dilation
+ * (3x3) or 0 (1x1).  `upsample` is a flag word: bit 0 = fused bilinear x2 upsample of x; bit 1 = also
+ * hand the launch Winograd-domain weights (3x3 stride-1 only; taken when the input is plain and
+ * stats_out is null); bit 2 = `affine`/`slope` are the EPILOGUE ([Cout][2] folded BatchNorm +
+ * activation, the eval-mode form) instead of a pending affine [Cin][2] on the input.
+ * stats_out [Cout][2] receives (sum, sumsq) of the raw output per channel when non-null.          */
 int vr_debug_conv2d(vr_handle h, const float* x, int N, int Cin, int H, int W, const float* w, int Cout,
                     int ksize, int stride, int dil_h, int dil_w, int upsample, const float* affine,
                     float slope, const float* bias, float* out, float* stats_out);

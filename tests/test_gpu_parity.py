@@ -92,6 +92,70 @@ def test_conv_kernel_vs_torch(vr, small, case):
     assert e1 < 1e-4 and e2 < 1e-4, 'BatchNorm partial sums off: %.3e %.3e' % (e1, e2)
 
 
+def _plain_conv_case(vr, handle, N, Cin, H, W, Cout, ks, stride, dh, dw, use_epi, slope, use_bias, wino, seed):
+    """Plain input (the eval-mode form): LDS-DMA kernel, or the Winograd kernel when `wino`."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / (Cin * ks * ks) ** 0.5
+    epi = torch.stack([torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.3], 1) if use_epi else None
+    bias = torch.randn(Cout, generator=g) if use_bias else None
+    pad = (dh, dw) if ks == 3 else (0, 0)
+    want = F.conv2d(x, w, bias, stride, pad, (dh, dw))
+    if epi is not None:
+        want = want * epi[:, 0].view(1, -1, 1, 1) + epi[:, 1].view(1, -1, 1, 1)
+        want = torch.where(want > 0, want, want * slope)
+    got = np.empty(tuple(want.shape), np.float32)
+    xn, wn = x.numpy(), w.numpy()
+    en = epi.numpy().copy() if epi is not None else None
+    bn = bias.numpy() if bias is not None else None
+    nat = vr.native
+    flags = (2 if wino else 0) | (4 if use_epi else 0)
+    nat.check(nat.lib().vr_debug_conv2d(
+        handle.h, nat.np_ptr(xn), N, Cin, H, W, nat.np_ptr(wn), Cout, ks, stride, dh, dw, flags,
+        nat.np_ptr(en) if en is not None else None, ctypes.c_float(slope if use_epi else 1.0),
+        nat.np_ptr(bn) if bn is not None else None, nat.np_ptr(got), None))
+    return float(np.abs(got - want.numpy()).max()) / float(want.abs().max())
+
+
+PLAIN_CASES = [
+    # N, Cin, H,  W,  Cout, ks, stride, dh, dw, epi, slope, bias
+    (2, 2, 16, 32, 16, 3, 1, 1, 1, 0, 1.0, 0),           # Cin < one chunk
+    (1, 10, 24, 64, 32, 3, 1, 1, 1, 1, 0.0, 0),
+    (2, 26, 40, 48, 32, 3, 1, 1, 1, 1, 0.01, 1),         # W not a multiple of 32, bias + epilogue
+    (1, 64, 17, 32, 64, 3, 1, 1, 1, 1, 0.0, 0),          # odd H
+    (1, 32, 32, 64, 128, 3, 1, 1, 1, 1, 0.01, 0),
+    (2, 97, 16, 64, 32, 3, 1, 1, 1, 1, 0.0, 0),          # dec1-like (Cin = 97)
+    (1, 192, 16, 32, 192, 3, 1, 1, 1, 0, 1.0, 0),
+    (3, 17, 20, 16, 48, 3, 1, 1, 1, 1, 0.0, 0),          # 16-wide tiles
+    (2, 16, 32, 64, 32, 3, 2, 1, 1, 1, 0.01, 0),         # stride 2
+    (1, 33, 34, 36, 96, 3, 2, 1, 1, 0, 1.0, 0),
+    (2, 8, 32, 32, 8, 3, 2, 1, 1, 1, 0.0, 0),            # stride 2 -> 16-wide output
+    (2, 32, 32, 16, 32, 3, 1, 4, 2, 1, 0.0, 0),          # ASPP dilations
+    (1, 64, 64, 16, 64, 3, 1, 8, 4, 1, 0.0, 0),
+    (2, 16, 32, 16, 16, 3, 1, 12, 6, 0, 1.0, 0),
+    (2, 40, 16, 32, 8, 1, 1, 1, 1, 1, 0.0, 0),           # 1x1
+    (1, 320, 32, 16, 64, 1, 1, 1, 1, 1, 0.0, 1),         # 1x1, 16-wide, K = 320
+    (1, 128, 5, 64, 256, 1, 1, 1, 1, 0, 1.0, 1),
+]
+
+
+@pytest.mark.parametrize('case', PLAIN_CASES, ids=[str(c) for c in PLAIN_CASES])
+def test_conv_dma_plain_input_vs_torch(vr, small, case):
+    rel = _plain_conv_case(vr, small[0]._handle, *case, wino=False, seed=hash(case) % 1000)
+    assert rel < 1e-4, 'conv max-abs/scale = %.3e' % rel
+
+
+@pytest.mark.parametrize('case', [c for c in PLAIN_CASES if c[5] == 3 and c[6] == 1 and c[7] == 1 and c[3] >= 32],
+                         ids=str)
+def test_conv_winograd_vs_torch(vr, small, case):
+    """F(2x2,3x3) in fp32: the transforms only add and halve; 1e-4 of the output scale is the same bar as
+    the direct kernels (measured ~1e-6)."""
+    rel = _plain_conv_case(vr, small[0]._handle, *case, wino=True, seed=hash(case) % 1000)
+    assert rel < 1e-4, 'winograd conv max-abs/scale = %.3e' % rel
+    direct = _plain_conv_case(vr, small[0]._handle, *case, wino=False, seed=hash(case) % 1000)
+    assert abs(rel - direct) < 1e-4
+
+
 def test_forward_taps_small_net(vr, small):
     """Every recorded intermediate of the small net vs the oracle's (localises a broken layer)."""
     model, sd, n_fft = small

@@ -336,6 +336,9 @@ bool wino_pick(const ConvArgs& a, const ConvShape& s, int* MT_out) {
     const long long tiles = (long long)a.N * ((a.Hout + 7) / 8) * ((a.Wout + 31) / 32);
     int MT = (a.CoutPad % 64 == 0) ? 64 : 32;
     if (MT == 64 && tiles * (a.CoutPad / 64) < 384) MT = 32;
+    // 32 couts per workgroup amortise the input transform poorly: with few input channels (padded to
+    // chunks of 8, no partial-chunk shortcut here) the direct LDS-DMA kernel is the faster one (measured)
+    if (MT == 32 && a.Cin < 40) return false;
     *MT_out = MT;
     return true;
 }

@@ -1081,9 +1081,13 @@ void Model::separate_wave_api(const float* wave, bool on_dev, long long L, int t
 // unit-test hook: one conv through the MFMA kernel with a single dense source
 // =====================================================================================================
 void Model::debug_conv(const float* x, int N, int Cin, int H, int W, const float* w_oihw, int Cout, int KS, int stride,
-                       int dh, int dw, int up, const float* aff, float slope, const float* bias, float* out,
+                       int dh, int dw, int flags, const float* aff, float slope, const float* bias, float* out,
                        float* stats_out) {
     VR_HIP(hipSetDevice(device));
+    // flags: bit 0 = fused x2 upsample; bit 1 = give the launch Winograd-domain weights (conv_wino.hip);
+    //        bit 2 = `aff`/`slope` describe the EPILOGUE ([Cout][2] folded BatchNorm + activation, eval mode)
+    const int up = flags & 1;
+    const bool want_wino = (flags & 2) != 0, epi = (flags & 4) != 0;
     const int KK = KS * KS, CoutPad = round_up(Cout, 32);
     const int Hin = up ? 2 * H : H, Win = up ? 2 * W : W;
     const int pad_h = KS == 1 ? 0 : dh, pad_w = KS == 1 ? 0 : dw;
@@ -1098,14 +1102,23 @@ void Model::debug_conv(const float* x, int N, int Cin, int H, int W, const float
     VR_HIP(hipMalloc(&dx, xin * 4)); VR_HIP(hipMalloc(&dw_, wk.size() * 4)); VR_HIP(hipMalloc(&dout, xout * 4));
     VR_HIP(hipMemcpy(dx, x, xin * 4, hipMemcpyHostToDevice));
     VR_HIP(hipMemcpy(dw_, wk.data(), wk.size() * 4, hipMemcpyHostToDevice));
-    if (aff) { VR_HIP(hipMalloc(&daff, (size_t)Cin * 8)); VR_HIP(hipMemcpy(daff, aff, (size_t)Cin * 8, hipMemcpyHostToDevice)); }
+    const size_t naff = epi ? Cout : Cin;
+    if (aff) { VR_HIP(hipMalloc(&daff, naff * 8)); VR_HIP(hipMemcpy(daff, aff, naff * 8, hipMemcpyHostToDevice)); }
     if (bias) { VR_HIP(hipMalloc(&dbias, (size_t)Cout * 4)); VR_HIP(hipMemcpy(dbias, bias, (size_t)Cout * 4, hipMemcpyHostToDevice)); }
     Tensor t;
     t.p = dx; t.N = N; t.C = Cin; t.H = H; t.W = W; t.sH = W; t.sC = (long long)H * W; t.sN = t.sC * Cin;
-    t.aff0 = daff; t.slope = slope;
+    if (!epi) { t.aff0 = daff; t.slope = slope; }
     ConvArgs a{};
     a.nsrc = 1; a.src[0] = make_src(t, up != 0, 0); a.c1 = a.c2 = Cin; a.Cin = Cin;
     a.w = dw_; a.bias = dbias; a.Cout = Cout; a.CoutPad = CoutPad;
+    if (epi && daff) { a.epi = daff; a.epi_slope = slope; }
+    float* dwino = nullptr;
+    if (want_wino) {
+        VR_CHECK(KS == 3 && stride == 1 && dh == 1 && dw == 1, -2, "Winograd weights exist for 3x3 stride-1 convs only");
+        VR_HIP(hipMalloc(&dwino, (size_t)Cin * 16 * CoutPad * 4));
+        launch_wino_weights(dw_, dwino, Cin, CoutPad, stream);
+        a.wino = dwino;
+    }
     a.dst[0] = ConvDst{dout, (long long)Hout * Wout * Cout, (long long)Hout * Wout, (long long)Wout, 0};
     a.d1 = a.d2 = 1 << 30;
     a.N = N; a.Hout = Hout; a.Wout = Wout; a.Hin = Hin; a.Win = Win; a.pad_h = pad_h; a.pad_w = pad_w;
@@ -1124,7 +1137,7 @@ void Model::debug_conv(const float* x, int N, int Cin, int H, int W, const float
             stats_out[2 * c] = (float)s1; stats_out[2 * c + 1] = (float)s2;
         }
     }
-    hipFree(dx); hipFree(dw_); hipFree(dout); hipFree(daff); hipFree(dbias); hipFree(dpart);
+    hipFree(dx); hipFree(dw_); hipFree(dout); hipFree(daff); hipFree(dbias); hipFree(dpart); hipFree(dwino);
 }
 
 }  // namespace vr
