@@ -91,6 +91,12 @@ def cpu_baseline_infer(sd, frames=1292):
                       'STFT->separate(batch 4)->iSTFT x2, %.1f s wall' % (T, L / SR, -(-T // 128) + 1, dt)}
 
 
+CONV_FAMILY_INFER = ('conv family on v_mfma_f32_32x32x2_f32: conv_wino_kernel<*> (Winograd F(2x2,3x3), the 3x3 stride-1 '
+                     'layers) + conv_dma_kernel<*> (direct implicit GEMM: stride-2, dilated, 1x1, thin layers)')
+CONV_FAMILY_TRAIN = ('conv family on v_mfma_f32_32x32x2_f32: conv_ws_kernel<*> / conv_mfma_kernel<*> (forward + '
+                     'data gradient, fused BatchNorm/activation/upsample loader) + wgrad_ws_kernel<*> (weight gradient)')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -184,8 +190,9 @@ def main():
     import ctypes
     nat.check(nat.lib().vr_profile_begin(net._handle.h))
     step()
-    cms, cfl, cn = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
-    nat.check(nat.lib().vr_profile_end(net._handle.h, ctypes.byref(cms), ctypes.byref(cfl), ctypes.byref(cn)))
+    cms, cfl, cn, cby = ctypes.c_double(), ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
+    nat.check(nat.lib().vr_profile_end(net._handle.h, ctypes.byref(cms), ctypes.byref(cfl), ctypes.byref(cn),
+                                       ctypes.byref(cby)))
     achieved = cfl.value / (cms.value * 1e-3) / 1e12 if cms.value > 0 else 0.0
 
     # HBM traffic of the dominant kernel: rocprofv3 PMC passes of this same command (collected
@@ -209,12 +216,15 @@ def main():
                        'computed_frames_per_sec': world * crops * CROP * args.steps / dt,
                        'parallelism': 'replicas x%d (songs shard, no collective)' % world if args.mode == 'infer'
                        else 'dp%d (RCCL all-reduce of one flat fp32 gradient bucket)' % world},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel<*> (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM conv)',
+            'roofline': {'bound': 'mfma',
+                         'kernel': CONV_FAMILY_INFER if args.mode == 'infer' else CONV_FAMILY_TRAIN,
                          'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
                          'traffic_unit': 'HBM bytes per launch (mean over the conv launches of a step; rocprofv3 '
                                          'FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/r01_infer_pmc.json)',
-                         'algorithmic_bytes_per_launch': 1.1475e9 * crops / max(cn.value, 1) if args.mode == 'infer' else None,
+                         'algorithmic_bytes_per_launch': cby.value / max(cn.value, 1),
+                         'achieved_note': 'algorithmic FLOPs = 2 x multiply-adds of the direct convolutions / summed '
+                                          'launch durations (HIP events); the Winograd launches execute 2.25x fewer',
                          'launches_per_step': cn.value, 'kernel_ms_per_step': cms.value,
                          'algorithmic_gflop_per_step': cfl.value / 1e9},
         }

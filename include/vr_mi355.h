@@ -105,9 +105,11 @@ int vr_set_dropout(vr_handle h, int mode, uint64_t seed, const float* masks, int
 int vr_grad_arena(vr_handle h, float** device_ptr, int64_t* numel);
 
 /* ---- measurement hooks (bench.py) ----------------------------------------------------------- */
-/* Bracket subsequent calls: every MFMA-conv launch is timed with HIP events on the handle's stream. */
+/* Bracket subsequent calls: every MFMA-conv launch is timed with HIP events on the handle's stream.
+ * conv_flops = 2 x multiply-adds of the direct convolutions (the Winograd kernel performs fewer),
+ * conv_bytes = algorithmic HBM bytes (virtual input + weights + output of each launch, once each). */
 int vr_profile_begin(vr_handle h);
-int vr_profile_end(vr_handle h, double* conv_ms, double* conv_flops, int* conv_launches);
+int vr_profile_end(vr_handle h, double* conv_ms, double* conv_flops, int* conv_launches, double* conv_bytes);
 
 /* ---- test hooks (tests/ only) ---------------------------------------------------------------- */
 /* One convolution through the library's conv dispatcher: x [N,Cin,H,W], w OIHW, padding = dilation

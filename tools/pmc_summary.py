@@ -1,7 +1,12 @@
-"""Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in KB)."""
+"""Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in KB).
+Usage: pmc_summary.py fetch.db write.db [steps_in_pass out.json]  -- the JSON is what bench.py reads for
+`roofline.traffic` (conv family, FETCH_SIZE x2 = the gfx950 correction of MI355X_MICROARCH.md)."""
+import json
 import re
 import sqlite3
 import sys
+
+FAMILY = 'conv family (conv_wino + conv_dma + conv_ws + conv_mfma)'
 
 
 def load(path, counter):
@@ -9,7 +14,8 @@ def load(path, counter):
     out = {}
     for name, val in db.execute("select name, counter_value from pmc_events where counter_name=? order by start", (counter,)):
         name = re.sub(r'^void ', '', name)
-        name = 'conv family (conv_ws + conv_mfma)' if ('conv_mfma_kernel' in name or 'conv_ws_kernel' in name) else re.sub(r'\(.*$', '', name)[:60]
+        conv = any(k in name for k in ('conv_mfma_kernel', 'conv_ws_kernel', 'conv_dma_kernel', 'conv_wino_kernel'))
+        name = FAMILY if conv else re.sub(r'\(.*$', '', name)[:60]
         n, s = out.get(name, (0, 0.0))
         out[name] = (n + 1, s + val)
     return out
@@ -21,3 +27,16 @@ print('| kernel | launches | FETCH_SIZE MB (raw) | WRITE_SIZE MB (raw) |')
 print('|---|---|---|---|')
 for k in sorted(f, key=lambda k: -f[k][1]):
     print('| %s | %d | %.1f | %.1f |' % (k, f[k][0], f[k][1] / 1024, w.get(k, (0, 0))[1] / 1024))
+if len(sys.argv) > 4:
+    n, fk = f[FAMILY]
+    wk = w[FAMILY][1]
+    json.dump({
+        'command': 'VR_NO_SIDE_STREAM=1 VR_NO_SPLIT_BATCH=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py '
+                   '--steps 1 --warmup 0 --no-cpu-baseline (two separate passes, single stream so kernels do not overlap)',
+        'kernel': FAMILY, 'launches_in_pass': n, 'steps_in_pass': int(sys.argv[3]),
+        'fetch_size_kb_raw': fk, 'write_size_kb_raw': wk, 'fetch_correction': 2.0,
+        'note': 'gfx950 FETCH_SIZE reads 1/2 of streamed bytes (MI355X_MICROARCH.md, HBM section); calibrated in the first '
+                'round-1 pass on kernels with known traffic (thin_conv_kernel<2,true>: 369.1 MB algorithmic vs 176.0 MB '
+                'reported = 0.477; WRITE_SIZE matches: 11.5 MB vs 11.0 MB).',
+        'bytes_per_launch': (2.0 * fk + wk) * 1024.0 / n,
+    }, open(sys.argv[4], 'w'), indent=1)

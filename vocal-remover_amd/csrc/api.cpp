@@ -193,9 +193,9 @@ int vr_profile_begin(vr_handle h) {
     return guard([&] { h->m.profile_begin(); });
 }
 
-int vr_profile_end(vr_handle h, double* conv_ms, double* conv_flops, int* conv_launches) {
+int vr_profile_end(vr_handle h, double* conv_ms, double* conv_flops, int* conv_launches, double* conv_bytes) {
     NEED(h);
-    return guard([&] { h->m.profile_end(conv_ms, conv_flops, nullptr, conv_launches); });
+    return guard([&] { h->m.profile_end(conv_ms, conv_flops, conv_bytes, conv_launches); });
 }
 
 int vr_debug_conv2d(vr_handle h, const float* x, int N, int Cin, int H, int W, const float* w, int Cout, int ksize,

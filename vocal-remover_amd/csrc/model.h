@@ -89,7 +89,7 @@ struct BaseNetL {
 void merge_artifacts_weight(const std::vector<float>& fmin, std::vector<float>& weight, float thres, int min_range,
                             int fade);
 
-struct ProfileEntry { hipEvent_t e0, e1; double flops; int kind; std::string tag; };
+struct ProfileEntry { hipEvent_t e0, e1; double flops; int kind; std::string tag; double bytes = 0; };
 
 class Model {
 public:
@@ -133,7 +133,7 @@ public:
     bool profiling = false;
     std::vector<ProfileEntry> prof;
     void profile_begin();
-    void profile_end(double* conv_ms, double* conv_flops, double* other_ms, int* launches);
+    void profile_end(double* conv_ms, double* conv_flops, double* conv_bytes, int* launches);
 
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;          // eval mode: the high-band chain runs here

@@ -382,14 +382,14 @@ void Model::profile_begin() {
     profiling = true;
 }
 
-void Model::profile_end(double* conv_ms, double* conv_flops, double* other_ms, int* launches) {
+void Model::profile_end(double* conv_ms, double* conv_flops, double* conv_bytes, int* launches) {
     VR_HIP(hipStreamSynchronize(stream));
-    double cm = 0, cf = 0, om = 0;
+    double cm = 0, cf = 0, om = 0, cb = 0;
     int n = 0;
     for (auto& e : prof) {
         float ms = 0.f;
         VR_HIP(hipEventElapsedTime(&ms, e.e0, e.e1));
-        if (e.kind == 0) { cm += ms; cf += e.flops; ++n; } else om += ms;
+        if (e.kind == 0) { cm += ms; cf += e.flops; cb += e.bytes; ++n; } else om += ms;
         static const bool dump = getenv("VR_PROFILE_DUMP") != nullptr;       // per-launch table on stderr
         if (dump) fprintf(stderr, "[vr-prof] %-44s %9.1f us %8.2f GFLOP %7.1f TFLOP/s\n", e.tag.c_str(), ms * 1e3,
                           e.flops * 1e-9, ms > 0 ? e.flops / ms * 1e-9 : 0.0);
@@ -399,7 +399,8 @@ void Model::profile_end(double* conv_ms, double* conv_flops, double* other_ms, i
     profiling = false;
     if (conv_ms) *conv_ms = cm;
     if (conv_flops) *conv_flops = cf;
-    if (other_ms) *other_ms = om;
+    if (conv_bytes) *conv_bytes = cb;
+    (void)om;
     if (launches) *launches = n;
 }
 
@@ -530,6 +531,9 @@ Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs, int N, const T
         const double flops = 2.0 * N * (double)(batch_as_h ? 1 : a.Hout) * a.Wout * (double)L.Cout * L.Cin * L.KS * L.KS;
         record_begin(0, flops);
         if (profiling) {
+            // algorithmic HBM bytes of the launch: the virtual input, the 3x3/1x1 weights and the output, once each
+            prof.back().bytes = 4.0 * ((double)a.N * L.Cin * a.Hin * a.Win + (double)N * L.Cout * (batch_as_h ? 1 : a.Hout) * a.Wout +
+                                       (double)L.Cin * L.KS * L.KS * L.Cout);
             char tag[160];
             snprintf(tag, sizeof tag, "%s k%d s%d d%d ci%d co%d %dx%dx%d", L.name.c_str(), L.KS, L.stride, L.dh, L.Cin,
                      L.Cout, a.N, a.Hout, a.Wout);

@@ -39,7 +39,8 @@ _SIGNATURES = {
     'vr_grad_arena': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64)]),
     'vr_profile_begin': (ctypes.c_int, [ctypes.c_void_p]),
     'vr_profile_end': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
-                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
+                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int),
+                                      ctypes.POINTER(ctypes.c_double)]),
     'vr_debug_conv2d': (ctypes.c_int, [ctypes.c_void_p, c_f32p] + [ctypes.c_int] * 4 + [c_f32p] + [ctypes.c_int] * 6
                         + [c_f32p, ctypes.c_float, c_f32p, c_f32p, c_f32p]),
     'vr_debug_conv2d_backward': (ctypes.c_int, [ctypes.c_void_p, c_f32p] + [ctypes.c_int] * 4 + [c_f32p]
