@@ -178,7 +178,9 @@ private:
     void finalize_layout();
 
     // executor
-    struct SrcSpec { Tensor t; bool up = false; int bcastH = 0; };
+    // `plain`: training only -- dense [N][C][Hv][Wv] copy of the values the conv sees (BatchNorm, activation,
+    // dropout, upsample / broadcast applied), so that forward and weight gradient load it without arithmetic
+    struct SrcSpec { Tensor t; bool up = false; int bcastH = 0; float* plain = nullptr; };
     // ---- training tape: forward order == topological order, backward walks it in reverse ----
     enum TapeKind { TK_CONV, TK_AVGPOOL, TK_SQUEEZE, TK_LSTM, TK_DENSE_ACT };
     struct TapeRec {

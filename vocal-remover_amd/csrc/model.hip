@@ -451,6 +451,13 @@ void Model::build_fwd_args(Conv& L, const std::vector<SrcSpec>& srcs, int N, boo
         a.src[i] = make_src(sp.t, sp.up, sp.bcastH);
         const int vh = sp.up ? 2 * sp.t.H : (sp.bcastH ? sp.bcastH : sp.t.H);
         const int vw = sp.up ? 2 * sp.t.W : sp.t.W;
+        if (sp.plain) {                       // materialised view of the same values
+            ConvSrc& c = a.src[i];
+            c = ConvSrc{};
+            c.p = sp.plain; c.C = sp.t.C; c.H = vh; c.W = vw;
+            c.sH = vw; c.sC = (long long)vh * vw; c.sN = c.sC * sp.t.C;
+            c.hsplit = 1 << 30; c.slope = 1.f;
+        }
         if (Hin < 0) { Hin = vh; Win = vw; }
         // spec_utils.crop_center (lib/spec_utils.py:8-23) is the identity for every valid shape;
         // anything else is the reference's ValueError.
@@ -488,8 +495,29 @@ void Model::build_fwd_args(Conv& L, const std::vector<SrcSpec>& srcs, int N, boo
     a.pad_h = L.pad_h; a.pad_w = L.pad_w;
 }
 
-Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs, int N, const Tensor* out_view, const float* bias,
+Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs_in, int N, const Tensor* out_view, const float* bias,
                        bool batch_as_h) {
+    // Training: give the conv plain inputs (one element-wise / upsample pass per source) -- the forward conv
+    // then takes the LDS-DMA kernel and the weight gradient re-reads the same buffers without arithmetic.
+    std::vector<SrcSpec> srcs = srcs_in;
+    static const bool mat_enabled = !getenv("VR_NO_TRAIN_MAT");
+    if (training && mat_enabled) {
+        for (SrcSpec& sp : srcs) {
+            const Tensor& t = sp.t;
+            if (!(t.aff0 || t.aff1 || t.post || t.slope != 1.f || sp.up || sp.bcastH)) continue;
+            const int vh = sp.up ? 2 * t.H : (sp.bcastH ? sp.bcastH : t.H), vw = sp.up ? 2 * t.W : t.W;
+            float* buf = ws.allocf((size_t)t.N * t.C * vh * vw);
+            if (!dry) {
+                if (sp.up) launch_upsample2x(t, buf, stream);
+                else {
+                    Tensor v = t;
+                    if (sp.bcastH) { v.H = sp.bcastH; v.sH = 0; }
+                    launch_materialize(v, buf, stream);
+                }
+            }
+            sp.plain = buf;
+        }
+    }
     ConvArgs a;
     build_fwd_args(L, srcs, N, batch_as_h, a);
     a.bias = bias;

@@ -231,7 +231,8 @@ __global__ void materialize_kernel(Tensor x, float* out, long long total) {
     float sc, sh;
     load_aff(x, h, c, sc, sh);
     const float raw = x.p[(long long)n * x.sN + (long long)c * x.sC + (long long)h * x.sH + w];
-    out[gid] = act1(fmaf(raw, sc, sh), x.slope);
+    const float post = x.post ? x.post[n * x.C + c] : 1.f;        // Dropout2d keep-mask / 0.9
+    out[gid] = act1(fmaf(raw, sc, sh), x.slope) * post;
 }
 
 // Bilinear x2 upsample, align_corners=True (lib/layers.py:52 F.interpolate), of the activated tensor
@@ -272,6 +273,9 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(Tensor x, float* __rest
         const float v11 = act1(fmaf(r1[w1 + w1p], sc1, sh1), x.slope);
         o[j] = h0l * (w0l * v00 + w1l * v01) + h1l * (w0l * v10 + w1l * v11);
     }
+    const float post = x.post ? x.post[n * x.C + c] : 1.f;
+#pragma unroll
+    for (int j = 0; j < V; ++j) o[j] *= post;
     if constexpr (V == 4) reinterpret_cast<float4*>(out)[gid] = make_float4(o[0], o[1], o[2], o[3]);
     else reinterpret_cast<float2*>(out)[gid] = make_float2(o[0], o[1]);
 }
