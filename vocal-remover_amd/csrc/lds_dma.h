@@ -25,6 +25,12 @@ __device__ __forceinline__ void dma16(unsigned lds_base, unsigned voff, i32x4 rs
                  :: "s"(lds_base), "v"(voff), "s"(rsrc) : "memory");
 }
 
+// Dword form: lane l copies 4 B to LDS byte lds_base + 4*l (any 4-B aligned base: odd LDS pitches stay possible).
+__device__ __forceinline__ void dma4(unsigned lds_base, unsigned voff, i32x4 rsrc) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
+                 :: "s"(lds_base), "v"(voff), "s"(rsrc) : "memory");
+}
+
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ void dma_wait_and_barrier() {

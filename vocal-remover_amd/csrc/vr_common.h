@@ -115,6 +115,7 @@ struct WgradArgs {
     float* part;               // scratch [P][Cin][KS*KS][CoutPad]
     long long part_stride;
     int P, tiles_w, tiles_h, npt, nchunks, nct;
+    int dma;                   // 1: every source is a plain tensor -> the loader waves use LDS-DMA (no arithmetic)
 };
 double launch_wgrad(const WgradArgs& a, const ConvShape& s, float* grad_out, int accumulate, hipStream_t st);
 size_t wgrad_scratch_floats(const WgradArgs& a, const ConvShape& s);

@@ -12,6 +12,7 @@
 // (deterministic; no atomics).
 #include "conv_stage.h"
 #include "kernels.h"
+#include "lds_dma.h"
 
 namespace vr {
 
@@ -272,6 +273,69 @@ __global__ __launch_bounds__(256 + 64 * NPW) void wgrad_ws_kernel(const WgradArg
         // ------------------------------ producers ------------------------------
         const int pw = wave - 4, ptid = tid - 256;
         if (a.in.dbg & 4) __builtin_amdgcn_s_setprio(3);
+        if (a.dma) {
+            // plain sources: both tiles arrive by dword LDS-DMA (per-lane source offset, out-of-range = 0,
+            // odd LDS pitches allowed), the loader waves execute almost no VALU instructions
+            constexpr int NE = TH_in * TW_in, NPX = (NE + 63) / 64, NPD = TP / 64;
+            const unsigned lds0 = (unsigned)(size_t)smem;
+            for (int pt = t_begin; pt < t_end; ++pt) {
+                const unsigned xs_b = lds0 + (unsigned)(((pt - t_begin) & 1) * Ws::BUF * 4);
+                const unsigned ds_b = xs_b + Cfg::XS * 4;
+                if (a.in.dbg & 2) { __syncthreads(); continue; }
+                const int n = pt / tiles_per_img;
+                const int trem = pt - n * tiles_per_img;
+                const int h0 = (trem / a.tiles_w) * TH, w0 = (trem % a.tiles_w) * TW;
+                const int hbase = h0 * S - a.in.pad_h, wbase = w0 * S - a.in.pad_w;
+                unsigned zo[NPD], xh[NPX], xw[NPX];
+#pragma unroll
+                for (int q = 0; q < NPD; ++q) {
+                    const int px = q * 64 + lane;
+                    const int h = h0 + px / TW, w = w0 + px % TW;
+                    zo[q] = (h < a.in.Hout && w < a.in.Wout) ? (unsigned)(((long long)h * a.zH + w) * 4) : 0x80000000u;
+                }
+#pragma unroll
+                for (int q = 0; q < NPX; ++q) {
+                    const int e = q * 64 + lane;
+                    const int hi = hbase + e / TW_in, wi = wbase + e % TW_in;
+                    const bool ok = e < NE && hi >= 0 && hi < a.in.Hin && wi >= 0 && wi < a.in.Win;
+                    xh[q] = ok ? (unsigned)hi : 0u;
+                    xw[q] = ok ? (unsigned)(wi * 4) : 0x80000000u;
+                }
+#pragma unroll 1
+                for (int co = pw; co < MB * 32; co += NPW) {
+                    const int cg = co0 + co;
+                    const i32x4 zr = make_rsrc(a.dz + (long long)n * a.zN + (long long)(cg < a.Cout ? cg : 0) * a.zC,
+                                               cg < a.Cout ? 0x7FFFFFF0u : 0u);
+#pragma unroll
+                    for (int q = 0; q < NPD; ++q) dma4(ds_b + (unsigned)((co * DSs + q * 64) * 4), zo[q], zr);
+                }
+#pragma unroll 1
+                for (int cl = pw; cl < 32; cl += NPW) {
+                    const int ci = c0 + cl;
+                    const bool live = ci < a.in.Cin;
+                    const int cj = live ? ci : 0;
+                    const int si = (cj >= a.in.c1) + (cj >= a.in.c2);
+                    const int clc = cj - (si == 0 ? 0 : (si == 1 ? a.in.c1 : a.in.c2));
+                    const float* sp = si == 0 ? a.in.src[0].p : (si == 1 ? a.in.src[1].p : a.in.src[2].p);
+                    const long long sN = si == 0 ? a.in.src[0].sN : (si == 1 ? a.in.src[1].sN : a.in.src[2].sN);
+                    const long long sC = si == 0 ? a.in.src[0].sC : (si == 1 ? a.in.src[1].sC : a.in.src[2].sC);
+                    const unsigned sH4 =
+                        (unsigned)(si == 0 ? a.in.src[0].sH : (si == 1 ? a.in.src[1].sH : a.in.src[2].sH)) * 4u;
+                    const i32x4 xr = make_rsrc(sp + (long long)n * sN + (long long)clc * sC, live ? 0x7FFFFFF0u : 0u);
+#pragma unroll
+                    for (int q = 0; q < NPX; ++q) {
+                        const unsigned vo = xh[q] * sH4 + xw[q];
+                        if ((q + 1) * 64 <= NE) dma4(xs_b + (unsigned)((cl * CS + q * 64) * 4), vo, xr);
+                        else if (q * 64 + lane < NE) dma4(xs_b + (unsigned)((cl * CS + q * 64) * 4), vo, xr);
+                    }
+                }
+                dma_wait();
+                __syncthreads();             // tile pt has landed; consumers finished tile pt-1
+            }
+            __syncthreads();
+            if (MB == 1) __syncthreads();
+            return;
+        }
         for (int pt = t_begin; pt < t_end; ++pt) {
             float* Xs = smem + ((pt - t_begin) & 1) * Ws::BUF;
             float* Ds = Xs + Cfg::XS;
@@ -320,13 +384,30 @@ __global__ __launch_bounds__(256 + 64 * NPW) void wgrad_ws_kernel(const WgradArg
     else wg_consumer<KS, S, TH, TW, MB, 0>(a, smem, wave >> 1, lane, p, co0, c0, t_end - t_begin);
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, long long stride, int P, float* __restrict__ out,
-                                    long long n, int accumulate) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int p = 0; p < P; ++p) s += part[p * stride + i];
-    out[i] = accumulate ? out[i] + s : s;
+// Sums the P partial slabs: 64 elements x 4 slab groups per workgroup (slab p goes to group p & 3, each
+// thread keeps 4 loads in flight), groups added in a fixed order -> deterministic.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, long long stride, int P,
+                                                           float* __restrict__ out, long long n, int accumulate) {
+    __shared__ float red[4][64];
+    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+        int p = q;
+        for (; p + 12 < P; p += 16) {
+            s0 += part[(long long)p * stride + i];
+            s1 += part[(long long)(p + 4) * stride + i];
+            s2 += part[(long long)(p + 8) * stride + i];
+            s3 += part[(long long)(p + 12) * stride + i];
+        }
+        for (; p < P; p += 4) s0 += part[(long long)p * stride + i];
+    }
+    red[q][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (q == 0 && i < n) {
+        const float s = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        out[i] = accumulate ? out[i] + s : s;
+    }
 }
 
 struct WgTile { int TH, TW, MB; bool ws; };
@@ -361,7 +442,7 @@ void wgrad_plan(WgradArgs& a, const ConvShape& s) {
     a.nchunks = (a.in.Cin + 31) / 32;
     a.nct = a.CoutPad / (32 * t.MB);
     a.part_stride = (long long)a.in.Cin * s.KS * s.KS * a.CoutPad;
-    long long P = 1024 / ((long long)a.nchunks * a.nct);
+    long long P = 512 / ((long long)a.nchunks * a.nct);
     if (P < 1) P = 1;
     if (P > a.npt) P = a.npt;
     const long long cap = (64LL << 20) / a.part_stride;       // scratch <= 256 MB
@@ -419,6 +500,17 @@ double launch_wgrad(const WgradArgs& a_in, const ConvShape& s, float* grad_out, 
     const WgTile t = wg_pick(a, s);
     VR_CHECK(a.part != nullptr, -2, "wgrad needs a scratch slab");
     {
+        static const bool dma_on = !getenv("VR_NO_WGRAD_DMA");
+        bool plain = dma_on;
+        for (int i = 0; i < a.in.nsrc && plain; ++i) {
+            const ConvSrc& c = a.in.src[i];
+            plain = !c.aff0 && !c.aff1 && !c.post && !c.up && !c.zins && c.slope == 1.f &&
+                    (long long)c.H * (c.sH > 0 ? c.sH : 1) * 4 < 0x7FFFFFF0LL;
+        }
+        plain = plain && (long long)a.in.Hout * a.zH * 4 < 0x7FFFFFF0LL;
+        a.dma = plain ? 1 : 0;
+    }
+    {
         static const int dbg = [] { const char* e = getenv("VR_WG_DBG"); return e ? atoi(e) : 0; }();
         a.in.dbg = dbg;
     }
@@ -443,7 +535,7 @@ double launch_wgrad(const WgradArgs& a_in, const ConvShape& s, float* grad_out, 
         throw Error(-2, "unsupported wgrad shape");
     }
     const long long n = a.part_stride;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.part, a.part_stride,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, a.part, a.part_stride,
                        a.P, grad_out, n, accumulate);
     VR_HIP(hipGetLastError());
     return 2.0 * a.in.N * (double)a.in.Hout * a.in.Wout * (double)a.Cout * a.in.Cin * s.KS * s.KS;
