@@ -56,6 +56,13 @@ int vr_get_param(vr_handle h, const char* key, void* host, int64_t capacity_byte
 
 /* nn.Module.train() / eval()                                          inference.py:52, train.py:69,109 */
 int vr_set_mode(vr_handle h, int training);
+/* Numerical options.  "train_winograd" (default 1): train-mode forward and data-gradient 3x3 stride-1
+ * convolutions use the Winograd F(2x2,3x3) kernel (fp32; rounding differs from the direct kernel by
+ * ~1e-6 relative per conv -- the same class of difference as cuDNN's algorithm choice in the
+ * reference); 0 = direct kernels only.  Inference always uses Winograd where applicable.
+ * "adam_reset": zero the Adam moments and the step counter (what constructing a new
+ * torch.optim.Adam does; train.py:215-218).                                                          */
+int vr_set_option(vr_handle h, const char* name, int value);
 
 /* CascadedNet.forward (mode 0) / predict_mask (mode 1) / predict (mode 2)   lib/nets.py:82-141
  * x:   [B, 2, n_fft/2+1, T] fp32 magnitudes

@@ -80,10 +80,11 @@ def _rel(a, b):
     return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
 
 
-def test_train_step_vs_fp64_oracle(small_train):
+@pytest.fixture(scope='module')
+def oracle_step(small_train):
+    """The CPU oracle's train step in fp64 (the reference, pinned in test_oracle_vs_reference.py) and in fp32
+    (its own rounding noise, which calibrates the tolerance), computed once."""
     model, sd = small_train
-    model.load_state_dict(sd)
-    model.train()
     B, T = 4, 128
     X, y = train_step.synth_batch(B, T=T, n_fft=N_FFT, seed=5)
     masks = train_step.dropout_masks(B, seed=9, nout=NOUT)
@@ -92,7 +93,20 @@ def test_train_step_vs_fp64_oracle(small_train):
                                             dropout={k: v.double() for k, v in masks.items()})
     sd32 = weights.clone_state_dict(sd)
     loss32, g32 = train_step.loss_and_grads(sd32, X, y, n_fft=N_FFT, dropout=masks)
+    return X, y, masks, sd64, loss64, g64, g32
 
+
+@pytest.mark.parametrize('winograd', [0, 1], ids=['direct', 'winograd'])
+def test_train_step_vs_fp64_oracle(small_train, oracle_step, winograd):
+    """winograd=0: direct MFMA kernels only.  winograd=1 (the library default): the 3x3 stride-1 forward and
+    data-gradient convs use Winograd F(2x2,3x3), whose fp32 rounding differs by ~1e-6 per conv; the error
+    DISTRIBUTION must stay that of the fp32 CPU oracle (median / p95 bars unchanged), only the bar for
+    cancellation-dominated tiny tensors (a 1-element BatchNorm bias) is wider."""
+    model, sd = small_train
+    X, y, masks, sd64, loss64, g64, g32 = oracle_step
+    model.load_state_dict(sd)
+    model.train()
+    model.set_option('train_winograd', winograd)
     model.set_dropout_masks(masks)
     model.zero_grad()
     loss, mask = model.train_step(X.to('cuda:0'), y.to('cuda:0'), 1, return_mask=True)
@@ -110,7 +124,8 @@ def test_train_step_vs_fp64_oracle(small_train):
         e_gpu, e_cpu = _rel(grads[k], g64[k]), _rel(g32[k], g64[k])
         report.append((e_gpu, e_cpu, k))
         # tiny tensors (a 1-element BatchNorm bias) have no averaging: their relative error is luck
-        tol = max(5 * e_cpu, 3e-2) if g64[k].numel() >= 16 else max(5 * e_cpu, 0.15)
+        tiny = max(8 * e_cpu, 0.5) if winograd else max(5 * e_cpu, 0.15)
+        tol = max(5 * e_cpu, 3e-2) if g64[k].numel() >= 16 else tiny
         if e_gpu > tol:
             bad.append('%s gpu %.3e cpu-fp32 %.3e' % (k, e_gpu, e_cpu))
     report.sort(reverse=True)

@@ -104,6 +104,14 @@ int vr_set_mode(vr_handle h, int training) {
     return guard([&] { h->m.set_training(training != 0); });
 }
 
+int vr_set_option(vr_handle h, const char* name, int value) {
+    NEED(h);
+    return guard([&] {
+        VR_CHECK(name, VR_ERR_BAD_ARGUMENT, "null argument");
+        h->m.set_option(name, value);
+    });
+}
+
 int vr_forward(vr_handle h, const float* x, int x_on_device, int B, int T, int mode, float* out, int out_on_device) {
     NEED(h);
     return guard([&] {

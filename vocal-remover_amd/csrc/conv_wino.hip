@@ -41,7 +41,7 @@ struct WinoCfg {
     static constexpr int NWP = WS / 4, NWPASS = NWP / 512;             // 16-B weight pieces per wave-pass
     static constexpr int MP = 33;                                      // epilogue exchange pitch
     static_assert(NWP % 512 == 0, "weight slab splits evenly over 8 waves");
-    static_assert(16 * 32 * MP <= LDS_FLOATS && LDS_BYTES <= 160 * 1024, "LDS");
+    static_assert(16 * 32 * MP + 2 * MT <= LDS_FLOATS && LDS_BYTES <= 160 * 1024, "LDS");
 };
 
 template <int MT>
@@ -213,8 +213,8 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
 
     // ---------------- epilogue: gather the 16 frequencies per (cout, tile) through LDS, A^T M A ------------
     float* Mx = smem;                                                  // [16][32][MP]
-    float* dbase = a.dst[0].p + (long long)n * a.dst[0].sN;
-    const int dacc = a.dst[0].accumulate;
+    float* stat = smem + 16 * 32 * MP;                                 // [MT][2] BatchNorm partial sums (training)
+    if (a.part && tid < 2 * MT) stat[tid] = 0.f;                       // (ordered by the first pass's barriers)
 #pragma unroll
     for (int mi = 0; mi < WM; ++mi) {
 #pragma unroll
@@ -249,23 +249,52 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
                 const int co = co0 + mi * 32 + col;
                 const int T = ni * 32 + tl;
                 const int ho = h0 + 2 * (T >> 4), wo = w0 + 2 * (T & 15);
-                if (co < a.Cout && a.dst[0].p) {
-                    const float b = a.bias ? a.bias[co] : 0.f;
-                    float esc = 1.f, esh = 0.f, eslope = 1.f;
-                    if (a.epi) { esc = a.epi[2 * co]; esh = a.epi[2 * co + 1]; eslope = a.epi_slope; }
+                const int cc = co < a.Cout ? co : a.Cout - 1;
+                const float b = a.bias ? a.bias[cc] : 0.f;
+                float esc = 1.f, esh = 0.f, eslope = 1.f;
+                if (a.epi) { esc = a.epi[2 * cc]; esh = a.epi[2 * cc + 1]; eslope = a.epi_slope; }
+                // destination segment of this cout (the data gradient of a virtual concat has up to three)
+                const int seg = (co >= a.d1) + (co >= a.d2);
+                const int cod = co - (seg == 0 ? 0 : (seg == 1 ? a.d1 : a.d2));
+                float* dp = seg == 0 ? a.dst[0].p : (seg == 1 ? a.dst[1].p : a.dst[2].p);
+                const long long dN = seg == 0 ? a.dst[0].sN : (seg == 1 ? a.dst[1].sN : a.dst[2].sN);
+                const long long dC = seg == 0 ? a.dst[0].sC : (seg == 1 ? a.dst[1].sC : a.dst[2].sC);
+                const long long dH = seg == 0 ? a.dst[0].sH : (seg == 1 ? a.dst[1].sH : a.dst[2].sH);
+                const int dacc = seg == 0 ? a.dst[0].accumulate : (seg == 1 ? a.dst[1].accumulate : a.dst[2].accumulate);
+                float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-                    for (int dr = 0; dr < 2; ++dr) {
-                        if (ho + dr >= a.Hout) continue;
-                        float* q = dbase + (long long)co * a.dst[0].sC + (long long)(ho + dr) * a.dst[0].sH + wo;
+                for (int dr = 0; dr < 2; ++dr) {
 #pragma unroll
-                        for (int dc = 0; dc < 2; ++dc) {
-                            if (wo + dc >= a.Wout) continue;
-                            const float v = act_apply(fmaf(y[dr][dc] + b, esc, esh), eslope);
-                            q[dc] = dacc ? q[dc] + v : v;
+                    for (int dc = 0; dc < 2; ++dc) {
+                        const float v = y[dr][dc] + b;
+                        const bool in = ho + dr < a.Hout && wo + dc < a.Wout;
+                        if (in) { t1 += v; t2 = fmaf(v, v, t2); }
+                        if (in && co < a.Cout && dp) {
+                            float* q = dp + (long long)n * dN + (long long)cod * dC + (long long)(ho + dr) * dH + wo + dc;
+                            const float o = act_apply(fmaf(v, esc, esh), eslope);
+                            *q = dacc ? *q + o : o;
                         }
                     }
                 }
+                if (a.part) {                                           // sum over the 32 tiles of this half-wave
+#pragma unroll
+                    for (int off = 16; off >= 1; off >>= 1) {
+                        t1 += __shfl_xor(t1, off, 64);
+                        t2 += __shfl_xor(t2, off, 64);
+                    }
+                    if (tl == 0) {                                      // (cout, pass) pairs are unique: no race
+                        stat[(mi * 32 + col) * 2 + 0] += t1;
+                        stat[(mi * 32 + col) * 2 + 1] += t2;
+                    }
+                }
             }
+        }
+    }
+    if (a.part) {
+        lds_barrier();
+        if (tid < MT && co0 + tid < a.Cout) {
+            a.part[((long long)pt * a.Cout + co0 + tid) * 2 + 0] = stat[tid * 2 + 0];
+            a.part[((long long)pt * a.Cout + co0 + tid) * 2 + 1] = stat[tid * 2 + 1];
         }
     }
 }
@@ -319,14 +348,13 @@ static void wino_launch(const ConvArgs& a, hipStream_t st) {
     VR_HIP(hipGetLastError());
 }
 
-// True when the launch can take the Winograd kernel (forward 3x3 stride-1, plain inputs, one destination,
-// no BatchNorm statistics wanted, transformed weights available).
+// True when the launch can take the Winograd kernel (3x3 stride-1 forward or data gradient, plain inputs,
+// transformed weights available).
 bool wino_pick(const ConvArgs& a, const ConvShape& s, int* MT_out) {
     static const int enabled = getenv("VR_CONV_WINO") ? atoi(getenv("VR_CONV_WINO")) : 1;
-    if (!enabled || !a.wino || a.part) return false;
+    if (!enabled || !a.wino) return false;
     if (!(s.KS == 3 && s.stride == 1 && s.dil_h == 1 && s.dil_w == 1)) return false;
     if (a.pad_h != 1 || a.pad_w != 1 || a.Wout < 32 || (a.Win & 3)) return false;
-    if (a.d1 < a.CoutPad) return false;
     for (int i = 0; i < a.nsrc; ++i) {
         const ConvSrc& c = a.src[i];
         if (c.aff0 || c.aff1 || c.post || c.up || c.zins || c.slope != 1.f || c.W != a.Win) return false;

@@ -133,6 +133,9 @@ public:
     bool profiling = false;
     std::vector<ProfileEntry> prof;
     void profile_begin();
+    bool train_wino = true;                              // vr_set_option("train_winograd"): Winograd kernels in train mode
+    void set_option(const std::string& name, int value);
+    void reset_adam_state();
     void profile_end(double* conv_ms, double* conv_flops, double* conv_bytes, int* launches);
 
     hipStream_t stream = nullptr;
@@ -159,6 +162,9 @@ private:
     std::vector<BN*> bn_list;
     std::vector<Conv*> wino_list;                        // 3x3 stride-1 layers (conv_wino.hip)
     float* wino_arena = nullptr;
+    float* winot_arena = nullptr;                        // training: Winograd copies of the flipped/transposed weights
+    std::map<const Param*, float*> winot_of;
+    void refresh_wino(bool with_dgrad);
     BNFoldDesc* d_fold = nullptr;
     bool affine_dirty = true;
     void fold_eval_affines();

@@ -231,7 +231,7 @@ Model::~Model() {
     hipSetDevice(device);
     if (stream) hipStreamSynchronize(stream);
     hipFree(p_arena); hipFree(b_arena); hipFree(d_fold);
-    hipFree(ws.base); hipFree(io.base); hipFree(gs.base); hipFree(wino_arena);
+    hipFree(ws.base); hipFree(io.base); hipFree(gs.base); hipFree(wino_arena); hipFree(winot_arena);
     hipFree(g_arena); hipFree(m_arena); hipFree(v_arena); hipFree(wt_arena); hipFree(d_flip); hipFree(dropout_buf);
     hipFree(plan.twiddle); hipFree(plan.window);
     if (stream_b) {
@@ -317,7 +317,19 @@ void Model::fold_eval_affines() {
     int maxC = 1;
     for (BN* b : bn_list) maxC = std::max(maxC, std::max(b->C, b->bcast));
     launch_bn_fold_eval(d_fold, (int)bn_list.size(), maxC, 1e-5f, stream);
-    // the weights may have changed too (set_param / Adam): refresh the Winograd-domain copies G g G^T
+    refresh_wino(false);        // the weights may have changed too (set_param / Adam)
+    affine_dirty = false;
+}
+
+void Model::set_option(const std::string& name, int value) {
+    if (name == "train_winograd") train_wino = value != 0;
+    else if (name == "adam_reset") reset_adam_state();      // a freshly constructed torch.optim.Adam has no moments
+    else throw Error(-2, "unknown option: " + name);
+}
+
+// Winograd-domain copies (G g G^T) of every 3x3 stride-1 weight; with_dgrad: also of the flipped/transposed
+// weights the data gradient convolves with (train.hip keeps those in wt_of, refreshed once per step).
+void Model::refresh_wino(bool with_dgrad) {
     if (!wino_arena) {
         size_t total = 0;
         for (Conv* L : wino_list) total += (size_t)L->Cin * 16 * L->CoutPad;
@@ -326,7 +338,19 @@ void Model::fold_eval_affines() {
         for (Conv* L : wino_list) { L->wino = wino_arena + off; off += (size_t)L->Cin * 16 * L->CoutPad; }
     }
     for (Conv* L : wino_list) launch_wino_weights(L->w->dev, L->wino, L->Cin, L->CoutPad, stream);
-    affine_dirty = false;
+    if (!with_dgrad) return;
+    auto cin_pad = [](const Conv* L) { return (L->Cin + 31) / 32 * 32; };
+    if (!winot_arena) {
+        size_t total = 0;
+        for (Conv* L : wino_list) total += (size_t)L->Cout * 16 * cin_pad(L);
+        VR_HIP(hipMalloc(reinterpret_cast<void**>(&winot_arena), total * sizeof(float)));
+        size_t off = 0;
+        for (Conv* L : wino_list) { winot_of[L->w] = winot_arena + off; off += (size_t)L->Cout * 16 * cin_pad(L); }
+    }
+    for (Conv* L : wino_list) {
+        auto it = wt_of.find(L->w);
+        if (it != wt_of.end()) launch_wino_weights(it->second, winot_of[L->w], L->Cout, cin_pad(L), stream);
+    }
 }
 
 // =====================================================================================================
@@ -526,7 +550,7 @@ Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs_in, int N, cons
     // the raw tensor + pending affine: the batch statistics only exist after the whole conv has run.
     const bool fuse_epi = !training && L.bn != nullptr;
     if (fuse_epi) { a.epi = L.bn->affine; a.epi_slope = L.slope; }
-    if (!training) a.wino = L.wino;
+    a.wino = (training && !train_wino) ? nullptr : L.wino;   // (null until the first refresh_wino())
     Tensor o;
     if (batch_as_h) {
         o.N = N; o.C = L.Cout; o.H = 1; o.W = a.Wout;

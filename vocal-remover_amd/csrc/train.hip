@@ -137,6 +137,10 @@ void Model::bwd_conv(TapeRec& r) {
     d.src[0].zins = (L.stride == 2) ? 1 : 0;
     d.c1 = d.c2 = L.Cout; d.Cin = L.Cout;
     d.w = dry ? nullptr : wt_of[L.w];
+    {
+        auto it = winot_of.find(L.w);
+        d.wino = (!dry && train_wino && it != winot_of.end()) ? it->second : nullptr;
+    }
     d.bias = nullptr;
     d.Cout = L.Cin; d.CoutPad = round_up32(L.Cin);
     d.N = f.N; d.Hin = f.Hin; d.Win = f.Win; d.Hout = f.Hin; d.Wout = f.Win;
@@ -234,6 +238,10 @@ void Model::train_fwd_bwd_api(const float* X, const float* Y, bool on_dev, int B
     VR_CHECK(B > 0 && accumulation_steps > 0, -2, "batch and accumulation_steps must be positive");
     VR_CHECK(T > 0 && T % 16 == 0, -5, "h1_shape[3] must be greater than h2_shape[3] (frames must be a multiple of 16)");
     ensure_train_state();
+    // flipped/transposed weights for the data gradients + Winograd-domain copies of both, once per step
+    // (before the planning dry run: the kernel choice, hence the partial-statistics layout, depends on them)
+    launch_flip_transpose(d_flip, n_flip, stream);
+    refresh_wino(true);
     const size_t io_floats = (size_t)B * 2 * output_bin * T;
     const int Hm = max_bin;
     // ---- plan: dry run of forward + backward sizes both arenas ----------------------------------------
@@ -310,7 +318,7 @@ void Model::train_fwd_bwd_api(const float* X, const float* Y, bool on_dev, int B
     float* maskd = nullptr;
     if (mask_out) maskd = mask_on_dev ? mask_out : ws.allocf(io_floats);
     float* lossd = ws.allocf(16);
-    launch_flip_transpose(d_flip, n_flip, stream);
+
     run_all(xd, yd, maskd, lossd);
     float loss_h = 0.f;
     VR_HIP(hipMemcpyAsync(&loss_h, lossd, sizeof(float), hipMemcpyDeviceToHost, stream));
@@ -320,6 +328,16 @@ void Model::train_fwd_bwd_api(const float* X, const float* Y, bool on_dev, int B
     tape.clear();
     affine_dirty = true;
     dropout_dev = nullptr;
+}
+
+void Model::reset_adam_state() {
+    VR_HIP(hipSetDevice(device));
+    adam_step = 0;
+    if (m_arena) {
+        VR_HIP(hipMemsetAsync(m_arena, 0, p_floats * sizeof(float), stream));
+        VR_HIP(hipMemsetAsync(v_arena, 0, p_floats * sizeof(float), stream));
+        VR_HIP(hipStreamSynchronize(stream));
+    }
 }
 
 void Model::adam_step_api(float lr, float b1, float b2, float eps, float grad_scale) {

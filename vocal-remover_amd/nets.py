@@ -264,6 +264,11 @@ class CascadedNet(object):
             out[k] = torch.from_numpy(arr)
         return out
 
+    def set_option(self, name, value):
+        """Numerical options of the library (include/vr_mi355.h: vr_set_option), e.g. 'train_winograd'."""
+        h = self._need_handle()
+        native.check(native.lib().vr_set_option(h.h, name.encode(), int(value)))
+
     def set_dropout_masks(self, masks):
         """Inject Dropout2d keep-masks {'<net>.aspp': [B, 8c] tensor of 0 / (1/0.9)} (parity tests);
         None switches dropout off; an int seeds the library's own RNG."""

@@ -38,6 +38,7 @@ class Adam(object):
         self.model = refs[0].model
         self.param_groups = [{'lr': lr, 'betas': betas, 'eps': eps}]
         self.grad_scale = 1.0
+        self.model.set_option('adam_reset', 1)      # a new optimizer starts without moments, like torch.optim.Adam
 
     def step(self):
         g = self.param_groups[0]
