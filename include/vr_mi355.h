@@ -98,6 +98,21 @@ int vr_separate_wave(vr_handle h, const float* wave, int wave_on_device, int64_t
  * may be NULL): the full-width mask [B,2,bins,T] that model(X) returns.  Needs vr_set_mode(h, 1).    */
 int vr_train_step(vr_handle h, const float* X, const float* y, int on_device, int B, int T, int accumulation_steps,
                   float* loss_out, float* mask_out, int mask_on_device);
+/* Training input pipeline on the device: replaces the numeric part of
+ * lib/dataset.py VocalRemoverTrainingSet.__getitem__ (dataset.py:105-120) for a whole batch.
+ *   X, y           [B][T][2][bins] complex64 (re,im interleaved): the cropsize rows read from the cached .npy files
+ *                  (their on-disk row order; dataset.py:33-46,58-66), host or device
+ *   X_mix, y_mix   the mixup partners' rows (dataset.py:85-103), same layout; may be NULL when no sample mixes
+ *   desc[b]        coef (dataset.py:109), coef_mix (dataset.py:90-91), lam (np.random.beta, dataset.py:97) and flags:
+ *                  bit 0 aggressively_remove_vocal, 1 channel swap, 2 inst-only, 3 mixup,
+ *                  bits 4-6 = bits 0-2 for the partner (dataset.py:68-83 is applied to both independently)
+ *   reduction_weight [bins]  (train.py:197-205), NULL if no flag needs it
+ * Output: X_mag, y_mag [B][2][bins][T] fp32 = np.abs of the augmented crops, the tensors train_epoch consumes. */
+typedef struct vr_aug { float coef; float coef_mix; float lam; int flags; } vr_aug;
+int vr_augment_batch(vr_handle h, const float* X, const float* y, const float* X_mix, const float* y_mix, const vr_aug* desc,
+                     const float* reduction_weight, int B, int T, int bins, int in_on_device, float* X_mag, float* y_mag,
+                     int out_on_device);
+
 /* torch.optim.Adam(lr, betas=(b1,b2), eps, weight_decay=0).step()   train.py:215-218,95
  * grad_scale multiplies every gradient first (1/world_size after a SUM all-reduce).                */
 int vr_adam_step(vr_handle h, float lr, float b1, float b2, float eps, float grad_scale);

@@ -206,3 +206,36 @@ def test_train_epoch_lookalike_runs_and_learns(vr, small_train):
     assert losses[-1] < losses[0]
     assert np.isfinite(val)
     model.set_dropout_masks(None)
+
+
+# ---- training input pipeline on the device -----------------------------------------------
+def test_training_set_device_pipeline_vs_oracle(vr, small_train, tmp_path):
+    """vocal_remover_amd.dataset.VocalRemoverTrainingSet (host draws + vr_augment_batch) vs the numpy oracle of
+    lib/dataset.py:105-120 (pinned to the reference class in test_oracle_vs_reference.py), same numpy seeds."""
+    from oracle import dataset_np
+    from test_oracle_vs_reference import _reduction_weight, _synthetic_training_set
+    model, _ = small_train
+    bins = 65
+    ts = _synthetic_training_set(tmp_path, bins=bins, lengths=(130, 90, 200))
+    rw = _reduction_weight(bins)
+    ds = vr.dataset.VocalRemoverTrainingSet(ts * 2, cropsize=48, reduction_rate=0.5, reduction_weight=rw, mixup_rate=0.5,
+                                            mixup_alpha=0.4, model=model)
+    kinds = set()
+    for seed in range(20):
+        idx = [seed % len(ds), (seed * 5 + 1) % len(ds), (seed + 2) % len(ds)]
+        np.random.seed(seed)
+        want = [dataset_np.training_sample(ts * 2, i, 48, 0.5, rw, 0.5, 0.4) for i in idx]
+        np.random.seed(seed)
+        X, y = ds.batch(idx)
+        assert X.device.type == 'cuda' and tuple(X.shape) == (3, 2, bins, 48)
+        for b, (wx, wy) in enumerate(want):
+            scale = float(np.abs(wx).max()) + 1e-6
+            assert float(np.abs(X[b].cpu().numpy() - wx).max()) < 3e-6 * scale, (seed, b)
+            assert float(np.abs(y[b].cpu().numpy() - wy).max()) < 3e-6 * scale, (seed, b)
+            kinds.add(bool(np.abs(wx - wy).max() == 0))
+    # DataLoader look-alike: one pass over the set, device tensors, batch dimension handled
+    loader = vr.dataset.DeviceLoader(ds, batch_size=4, shuffle=True, generator=torch.Generator().manual_seed(0))
+    shapes = [tuple(Xb.shape) for Xb, _ in loader]
+    assert len(shapes) == len(loader) == 2 and shapes[0] == (4, 2, bins, 48) and shapes[1] == (2, 2, bins, 48)
+    x0, y0 = ds[1]
+    assert tuple(x0.shape) == (2, bins, 48) and x0.device.type == 'cuda'

@@ -128,3 +128,74 @@ def test_stft_restatement_vs_torch():
                          length=1024 * (T - 1)).numpy()
     assert np.abs(back - want_b).max() < 1e-5
     assert np.abs(back - wave[:, :back.shape[1]]).max() < 1e-5
+
+
+# ---- training sample pipeline: lib/dataset.py VocalRemoverTrainingSet ---------------------
+def _synthetic_training_set(tmp_path, bins=33, lengths=(90, 140, 75), seed=0):
+    """Cached spectrograms in the reference's on-disk format: [T, 2, bins] complex64 .npy + coef."""
+    rng = np.random.RandomState(seed)
+    ts = []
+    for i, T in enumerate(lengths):
+        pair = []
+        for tag in ('X', 'y'):
+            a = (rng.randn(T, 2, bins) + 1j * rng.randn(T, 2, bins)).astype(np.complex64) * (0.3 + i)
+            a[rng.rand(T, 2, bins) < 0.02] = 0          # exact zeros exercise angle(0)
+            path = str(tmp_path / ('song%d_%s.npy' % (i, tag)))
+            np.save(path, a)
+            pair.append((path, a))
+        coef = np.max([np.abs(pair[0][1]).max(), np.abs(pair[1][1]).max()])    # lib/dataset.py:214
+        ts.append([pair[0][0], pair[1][0], coef])
+    return ts
+
+
+def _reduction_weight(bins, level=0.2):
+    # train.py:197-205 with these bins
+    u, s = max(1, bins // 10), bins - bins // 8
+    return np.concatenate([np.linspace(0, 1, u, dtype=np.float32)[:, None],
+                           np.linspace(1, 0, s - u, dtype=np.float32)[:, None],
+                           np.zeros((bins - s, 1), dtype=np.float32)], axis=0) * level
+
+
+def test_training_sample_pipeline_matches_reference(reference_lib, tmp_path):
+    import importlib
+    from oracle import dataset_np
+    ref_ds_mod = importlib.import_module('lib.dataset')
+    ts = _synthetic_training_set(tmp_path)
+    rw = _reduction_weight(33)
+    ref = ref_ds_mod.VocalRemoverTrainingSet(ts * 2, cropsize=32, reduction_rate=0.5, reduction_weight=rw,
+                                             mixup_rate=0.5, mixup_alpha=0.4)
+    seen = set()
+    for seed in range(24):
+        idx = seed % len(ref)
+        np.random.seed(seed)
+        want_X, want_y = ref[idx]
+        nxt_ref = np.random.uniform()
+        np.random.seed(seed)
+        got_X, got_y = dataset_np.training_sample(ts * 2, idx, 32, 0.5, rw, 0.5, 0.4)
+        nxt = np.random.uniform()
+        assert nxt == nxt_ref, 'random stream consumed differently (seed %d)' % seed
+        assert got_X.shape == want_X.shape == (2, 33, 32)
+        assert np.abs(got_X - want_X).max() < 1e-6 and np.abs(got_y - want_y).max() < 1e-6
+        seen.add(bool(np.abs(want_X - want_y).max() == 0))
+    assert len(seen) >= 1
+
+
+def test_training_set_host_plan_consumes_rng_like_reference(reference_lib, tmp_path):
+    """The product's host half (vocal_remover_amd/dataset.py: plan) draws the same numbers in the same order."""
+    import importlib
+    import __graft_entry__
+    pkg = __graft_entry__.load_package()
+    ref_ds_mod = importlib.import_module('lib.dataset')
+    ts = _synthetic_training_set(tmp_path)
+    rw = _reduction_weight(33)
+    ref = ref_ds_mod.VocalRemoverTrainingSet(ts, 32, 0.5, rw, 0.5, 0.4)
+    mine = pkg.dataset.VocalRemoverTrainingSet(ts, 32, 0.5, rw, 0.5, 0.4)
+    for seed in range(16):
+        np.random.seed(seed)
+        ref[seed % 3]
+        a = np.random.uniform()
+        np.random.seed(seed)
+        mine.plan(seed % 3)
+        assert np.random.uniform() == a
+    with pytest.raises(RuntimeError):
+        mine[0]                                   # no model / no GPU: loud failure, no CPU fallback

@@ -165,6 +165,24 @@ int vr_train_step(vr_handle h, const float* X, const float* y, int on_device, in
     });
 }
 
+int vr_augment_batch(vr_handle h, const float* X, const float* y, const float* X_mix, const float* y_mix, const vr_aug* desc,
+                     const float* reduction_weight, int B, int T, int bins, int in_on_device, float* X_mag, float* y_mag,
+                     int out_on_device) {
+    NEED(h);
+    return guard([&] {
+        VR_CHECK(X && y && desc && X_mag && y_mag, VR_ERR_BAD_ARGUMENT, "null argument");
+        bool mix = false, red = false;
+        for (int b = 0; b < B; ++b) {
+            mix = mix || (desc[b].flags & 8);
+            red = red || (desc[b].flags & (1 | 16));
+        }
+        VR_CHECK(!mix || (X_mix && y_mix), VR_ERR_BAD_ARGUMENT, "mixup flagged but no partner crops given");
+        VR_CHECK(!red || reduction_weight, VR_ERR_BAD_ARGUMENT, "vocal reduction flagged but no reduction_weight given");
+        h->m.augment_api(X, y, X_mix, y_mix, desc, reduction_weight, B, T, bins, in_on_device != 0, X_mag, y_mag,
+                         out_on_device != 0);
+    });
+}
+
 int vr_adam_step(vr_handle h, float lr, float b1, float b2, float eps, float grad_scale) {
     NEED(h);
     return guard([&] { h->m.adam_step_api(lr, b1, b2, eps, grad_scale); });

@@ -43,6 +43,10 @@ void launch_add(const float* a, const float* b, float* out, int n, hipStream_t s
 
 // dense post-activation copy of a Tensor (debug taps / tests)
 void launch_materialize(const Tensor& x, float* out, hipStream_t st);
+// training input pipeline (augment.hip); layout-compatible with vr_aug in include/vr_mi355.h
+struct AugDesc { float coef, coef_mix, lam; int flags; };
+void launch_augment(const float2* X, const float2* Y, const float2* Xi, const float2* Yi, const AugDesc* desc, const float* rw,
+                    int B, int T, int bins, float* Xmag, float* Ymag, hipStream_t st);
 void launch_wino_weights(const float* w, float* u, int Cin, int CoutPad, hipStream_t st);   // U = G g G^T
 void launch_upsample2x(const Tensor& x, float* out, hipStream_t st);   // dense [N][C][2H][2W], activated
 

@@ -133,6 +133,9 @@ public:
     bool profiling = false;
     std::vector<ProfileEntry> prof;
     void profile_begin();
+    void augment_api(const float* Xc, const float* yc, const float* Xi, const float* yi, const void* desc, const float* rw,
+                     int B, int T, int bins, bool in_on_dev, float* Xmag, float* ymag, bool out_on_dev);
+    char* aug_buf = nullptr; size_t aug_cap = 0;         // staging of the training input pipeline
     bool train_wino = true;                              // vr_set_option("train_winograd"): Winograd kernels in train mode
     void set_option(const std::string& name, int value);
     void reset_adam_state();

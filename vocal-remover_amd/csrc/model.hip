@@ -231,7 +231,7 @@ Model::~Model() {
     hipSetDevice(device);
     if (stream) hipStreamSynchronize(stream);
     hipFree(p_arena); hipFree(b_arena); hipFree(d_fold);
-    hipFree(ws.base); hipFree(io.base); hipFree(gs.base); hipFree(wino_arena); hipFree(winot_arena);
+    hipFree(ws.base); hipFree(io.base); hipFree(gs.base); hipFree(wino_arena); hipFree(winot_arena); hipFree(aug_buf);
     hipFree(g_arena); hipFree(m_arena); hipFree(v_arena); hipFree(wt_arena); hipFree(d_flip); hipFree(dropout_buf);
     hipFree(plan.twiddle); hipFree(plan.window);
     if (stream_b) {

@@ -330,6 +330,50 @@ void Model::train_fwd_bwd_api(const float* X, const float* Y, bool on_dev, int B
     dropout_dev = nullptr;
 }
 
+// Training input pipeline (lib/dataset.py:105-120 after the random draws and the file reads), see augment.hip.
+void Model::augment_api(const float* Xc, const float* yc, const float* Xi, const float* yi, const void* desc, const float* rw,
+                        int B, int T, int bins, bool in_on_dev, float* Xmag, float* ymag, bool out_on_dev) {
+    VR_HIP(hipSetDevice(device));
+    VR_CHECK(B > 0 && T > 0 && bins > 0, -2, "augment: empty batch");
+    const size_t crop_b = (size_t)B * T * 2 * bins * sizeof(float2), out_b = (size_t)B * 2 * bins * T * sizeof(float);
+    const size_t desc_b = (size_t)B * sizeof(AugDesc), rw_b = (size_t)bins * sizeof(float);
+    auto up256 = [](size_t v) { return (v + 255) & ~size_t(255); };
+    size_t need = up256(desc_b) + up256(rw_b);
+    if (!in_on_dev) need += 4 * up256(crop_b);
+    if (!out_on_dev) need += 2 * up256(out_b);
+    if (need > aug_cap) {
+        VR_HIP(hipStreamSynchronize(stream));
+        if (aug_buf) VR_HIP(hipFree(aug_buf));
+        aug_buf = nullptr; aug_cap = 0;
+        VR_HIP(hipMalloc(reinterpret_cast<void**>(&aug_buf), need + (need >> 3)));
+        aug_cap = need + (need >> 3);
+    }
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = aug_buf + off; off += up256(bytes); return p; };
+    AugDesc* dd = reinterpret_cast<AugDesc*>(take(desc_b));
+    float* drw = reinterpret_cast<float*>(take(rw_b));
+    VR_HIP(hipMemcpyAsync(dd, desc, desc_b, hipMemcpyHostToDevice, stream));
+    if (rw) VR_HIP(hipMemcpyAsync(drw, rw, rw_b, hipMemcpyHostToDevice, stream));
+    const float* src[4] = {Xc, yc, Xi, yi};
+    const float2* dev[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 4; ++i) {
+        if (!src[i]) continue;
+        if (in_on_dev) { dev[i] = reinterpret_cast<const float2*>(src[i]); continue; }
+        char* p = take(crop_b);
+        VR_HIP(hipMemcpyAsync(p, src[i], crop_b, hipMemcpyHostToDevice, stream));
+        dev[i] = reinterpret_cast<const float2*>(p);
+    }
+    float* ox = out_on_dev ? Xmag : reinterpret_cast<float*>(take(out_b));
+    float* oy = out_on_dev ? ymag : reinterpret_cast<float*>(take(out_b));
+    launch_augment(dev[0], dev[1], dev[2] ? dev[2] : dev[0], dev[3] ? dev[3] : dev[1], dd, rw ? drw : nullptr, B, T, bins, ox, oy,
+                   stream);
+    if (!out_on_dev) {
+        VR_HIP(hipMemcpyAsync(Xmag, ox, out_b, hipMemcpyDeviceToHost, stream));
+        VR_HIP(hipMemcpyAsync(ymag, oy, out_b, hipMemcpyDeviceToHost, stream));
+    }
+    VR_HIP(hipStreamSynchronize(stream));
+}
+
 void Model::reset_adam_state() {
     VR_HIP(hipSetDevice(device));
     adam_step = 0;

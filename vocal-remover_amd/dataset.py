@@ -1,14 +1,170 @@
-"""Host-side crop geometry (the only piece of lib/dataset.py on the hot path)."""
+"""Host side of the training input pipeline (mirror of the reference's lib/dataset.py for the hot path).
+
+`make_padding` (lib/dataset.py:198-205) is shared with inference.  `VocalRemoverTrainingSet` keeps the
+reference's constructor and its on-disk format (cached `[T, 2, bins]` complex64 .npy + coef), draws the
+numpy random numbers in the reference's order and seek-reads the cropsize rows; everything numeric
+(/coef, aggressively_remove_vocal, channel swap, inst-only, mixup, abs, transpose) runs on the GPU as one
+kernel per batch (csrc/augment.hip through vr_augment_batch).  There is no CPU fallback.
+
+Drop-in at train.py:235-247: build the set with the same arguments plus the model, then iterate a
+`DeviceLoader(dataset, batch_size, shuffle=True)` instead of torch.utils.data.DataLoader -- it yields
+(X_batch, y_batch) already on the model's device, which is what train_epoch consumes (train.py:71-79).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import native
 
 
 def make_padding(width, cropsize, offset):
-    """dataset.make_padding (lib/dataset.py:198-205): left pad, right pad, roi size.
-
-    Note the reference adds a full extra roi on the right when width % roi == 0; kept.
-    """
     left = offset
     roi_size = cropsize - offset * 2
     if roi_size == 0:
         roi_size = cropsize
     right = roi_size - (width % roi_size) + left
     return left, right, roi_size
+
+
+class _Aug(ctypes.Structure):               # include/vr_mi355.h: vr_aug
+    _fields_ = [('coef', ctypes.c_float), ('coef_mix', ctypes.c_float), ('lam', ctypes.c_float), ('flags', ctypes.c_int)]
+
+
+def _npy_header(path):
+    with open(path, 'rb') as f:
+        np.lib.format.read_magic(f)
+        shape, fortran, dtype = np.lib.format.read_array_header_1_0(f)
+        if fortran:
+            raise AssertionError('Fortran order arrays are not supported')       # lib/dataset.py:38
+        return shape, dtype, f.tell()
+
+
+def _read_rows(path, start_row, n_rows, out):
+    """Rows [start_row, start_row+n_rows) of the cached spectrogram straight into `out` ([T, 2, bins] complex64)."""
+    shape, dtype, data_off = _npy_header(path)
+    if dtype != np.complex64 or tuple(shape[1:]) != tuple(out.shape[1:]):
+        raise ValueError('%s: expected complex64 rows of shape %s, found %s %s' % (path, out.shape[1:], dtype, shape[1:]))
+    row_bytes = int(np.prod(shape[1:])) * dtype.itemsize
+    with open(path, 'rb') as f:
+        f.seek(data_off + start_row * row_bytes)
+        got = f.readinto(out.reshape(-1).view(np.uint8))
+    if got != n_rows * row_bytes:
+        raise ValueError('%s: short read (%d of %d bytes)' % (path, got, n_rows * row_bytes))
+
+
+class VocalRemoverTrainingSet(object):
+    """lib/dataset.py:15-120 with the numeric part on the GPU.  `model` is the vocal_remover_amd CascadedNet
+    whose device (and HIP stream) the batches are produced on."""
+
+    def __init__(self, training_set, cropsize, reduction_rate, reduction_weight, mixup_rate, mixup_alpha, model=None):
+        self.training_set = training_set
+        self.cropsize = cropsize
+        self.reduction_rate = reduction_rate
+        self.reduction_weight = None if reduction_weight is None else \
+            np.ascontiguousarray(np.asarray(reduction_weight, np.float32).reshape(-1))
+        self.mixup_rate = mixup_rate
+        self.mixup_alpha = mixup_alpha
+        self.model = model
+
+    def __len__(self):
+        return len(self.training_set)
+
+    def read_npy_shape(self, path):
+        return _npy_header(path)[0]
+
+    # ---- random decisions, in the reference's order (lib/dataset.py:58-120) -------------------------
+    def _draw_aug(self):
+        flags = 0
+        if np.random.uniform() < self.reduction_rate:
+            flags |= 1
+        if np.random.uniform() < 0.5:
+            flags |= 2
+        if np.random.uniform() < 0.01:
+            flags |= 4
+        return flags
+
+    def plan(self, idx):
+        X_path, y_path, coef = self.training_set[idx]
+        n_rows = self.read_npy_shape(X_path)[0]
+        p = {'paths': (X_path, y_path), 'coef': float(coef), 'start': int(np.random.randint(0, n_rows - self.cropsize))}
+        p['flags'] = self._draw_aug()
+        p['mix'] = None
+        if np.random.uniform() < self.mixup_rate:
+            j = int(np.random.randint(0, len(self)))
+            Xj, yj, coef_j = self.training_set[j]
+            nj = self.read_npy_shape(Xj)[0]
+            m = {'paths': (Xj, yj), 'coef': float(coef_j), 'start': int(np.random.randint(0, nj - self.cropsize))}
+            m['flags'] = self._draw_aug()
+            m['lam'] = float(np.random.beta(self.mixup_alpha, self.mixup_alpha))
+            p['mix'] = m
+        return p
+
+    # ---- batch assembly + the device kernel ---------------------------------------------------------------
+    def batch(self, indices):
+        if self.model is None:
+            raise RuntimeError('VocalRemoverTrainingSet needs the model (its device runs the augmentation); no CPU fallback')
+        h = self.model._need_handle()
+        plans = [self.plan(i) for i in indices]
+        B, T = len(plans), self.cropsize
+        bins = int(self.read_npy_shape(plans[0]['paths'][0])[2])
+        X = np.empty((B, T, 2, bins), np.complex64)
+        y = np.empty((B, T, 2, bins), np.complex64)
+        any_mix = any(p['mix'] is not None for p in plans)
+        Xm = np.zeros((B, T, 2, bins), np.complex64) if any_mix else None
+        ym = np.zeros((B, T, 2, bins), np.complex64) if any_mix else None
+        desc = (_Aug * B)()
+        need_rw = False
+        for b, p in enumerate(plans):
+            _read_rows(p['paths'][0], p['start'], T, X[b])
+            _read_rows(p['paths'][1], p['start'], T, y[b])
+            flags, coef_mix, lam = p['flags'], 1.0, 1.0
+            if p['mix'] is not None:
+                m = p['mix']
+                _read_rows(m['paths'][0], m['start'], T, Xm[b])
+                _read_rows(m['paths'][1], m['start'], T, ym[b])
+                flags |= 8 | (m['flags'] << 4)
+                coef_mix, lam = m['coef'], m['lam']
+            need_rw = need_rw or bool(flags & (1 | 16))
+            desc[b] = _Aug(p['coef'], coef_mix, lam, flags)
+        if need_rw and self.reduction_weight is None:
+            raise ValueError('reduction_rate > 0 needs reduction_weight (train.py:197-205)')
+        dev = torch.device('cuda', h.device)
+        X_mag = torch.empty((B, 2, bins, T), dtype=torch.float32, device=dev)
+        y_mag = torch.empty((B, 2, bins, T), dtype=torch.float32, device=dev)
+        rw = self.reduction_weight
+        native.check(native.lib().vr_augment_batch(
+            h.h, native.np_ptr(X), native.np_ptr(y), native.np_ptr(Xm) if any_mix else None,
+            native.np_ptr(ym) if any_mix else None, ctypes.cast(desc, ctypes.c_void_p),
+            native.np_ptr(rw) if rw is not None else None, B, T, bins, 0,
+            ctypes.c_void_p(X_mag.data_ptr()), ctypes.c_void_p(y_mag.data_ptr()), 1))
+        return X_mag, y_mag
+
+    def __getitem__(self, idx):
+        X_mag, y_mag = self.batch([idx])
+        return X_mag[0], y_mag[0]
+
+
+class DeviceLoader(object):
+    """Iterable stand-in for torch.utils.data.DataLoader(dataset, batch_size, shuffle) (train.py:242-247):
+    yields (X_batch, y_batch) device tensors produced by one vr_augment_batch call per batch."""
+
+    def __init__(self, dataset, batch_size=1, shuffle=False, drop_last=False, generator=None):
+        self.dataset = dataset
+        self.batch_size = int(batch_size)
+        self.shuffle = shuffle
+        self.drop_last = drop_last
+        self.generator = generator
+
+    def __len__(self):
+        n = len(self.dataset)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        n = len(self.dataset)
+        order = torch.randperm(n, generator=self.generator).tolist() if self.shuffle else list(range(n))
+        for i in range(0, n, self.batch_size):
+            idx = order[i:i + self.batch_size]
+            if self.drop_last and len(idx) < self.batch_size:
+                break
+            yield self.dataset.batch(idx)
