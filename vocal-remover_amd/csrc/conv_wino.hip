@@ -171,7 +171,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
         if (k + 1 < nchunk) issue_chunk(k + 1);
         const float* Ws = WsB + (k & 1) * Cfg::WS + (2 * wave) * CK * MT + aoff;
         const float* Vs = VsB + (k & 1) * Cfg::VS + (2 * wave) * CK * NT + boff;
-        {
+        if (a.dbg != 2) {
             // 8 k-steps (2 frequencies x 4 channel pairs), operands of step s+1 read before the MFMAs of step s
             float av[WM], bv[2];
 #pragma unroll
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
         }
         if (k + 1 < nchunk) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's channel of chunk k+1 has landed
-            transform(k + 1);
+            if (a.dbg != 3) transform(k + 1);
         }
         lds_barrier();
     }
