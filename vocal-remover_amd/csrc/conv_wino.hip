@@ -35,7 +35,11 @@ struct WinoCfg {
     static constexpr int XS = CK * CSX;                                // raw input rows (single buffer)
     static constexpr int WS = 16 * CK * MT;                            // U slab   [f][cl][m]
     static constexpr int VS = 16 * CK * NT;                            // V slab   [f][cl][tile]
-    static constexpr int LDS_FLOATS = XS + 2 * WS + 2 * VS;
+    // 32 couts per workgroup: half the MFMA work per block, so the prologue (first DMA) and the epilogue weigh
+    // twice as much and must overlap ANOTHER workgroup's main loop.  One V buffer (at the price of a second
+    // barrier per chunk) brings the LDS footprint to 78 KB = two workgroups per CU.
+    static constexpr int NVB = MT == 32 ? 1 : 2;
+    static constexpr int LDS_FLOATS = XS + 2 * WS + NVB * VS;
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
     static constexpr int NPIECE = CSX / 4, NPASS = (NPIECE + 63) / 64;
     static constexpr int NWP = WS / 4, NWPASS = NWP / 512;             // 16-B weight pieces per wave-pass
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
     const int xpo = wave * CSX + (2 * (lane >> 4)) * TWq + 2 * (lane & 15) + XS0;
     auto transform = [&](int k) {
         const float* xp = Xraw + xpo;
-        float* V = VsB + (k & 1) * Cfg::VS + wave * NT + lane;      // + f * CK * NT
+        float* V = VsB + (k % Cfg::NVB) * Cfg::VS + wave * NT + lane;      // + f * CK * NT
         float t[4][4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
     for (int k = 0; k < nchunk; ++k) {
         if (k + 1 < nchunk) issue_chunk(k + 1);
         const float* Ws = WsB + (k & 1) * Cfg::WS + (2 * wave) * CK * MT + aoff;
-        const float* Vs = VsB + (k & 1) * Cfg::VS + (2 * wave) * CK * NT + boff;
+        const float* Vs = VsB + (k % Cfg::NVB) * Cfg::VS + (2 * wave) * CK * NT + boff;
         if (a.dbg != 2) {
             // 8 k-steps (2 frequencies x 4 channel pairs), operands of step s+1 read before the MFMAs of step s
             float av[WM], bv[2];
@@ -205,6 +209,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
             }
         }
         if (k + 1 < nchunk) {
+            if (Cfg::NVB == 1) lds_barrier();                              // every wave is done reading V(k)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's channel of chunk k+1 has landed
             if (a.dbg != 3) transform(k + 1);
         }
