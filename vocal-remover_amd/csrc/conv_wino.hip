@@ -62,7 +62,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
     const int xcd = id & 7;
     const int rr = id >> 3;
     const int ct = rr % a.nct;
-    const int pt = (rr / a.nct) * 8 + xcd;
+    const int pt = (rr / a.nct) * 8 + xcd;       // (a contiguous tile range per XCD was measured: no difference)
     if (pt >= a.npt) return;
     const int tiles_per_img = a.tiles_h * a.tiles_w;
     const int n = pt / tiles_per_img;
@@ -371,7 +371,8 @@ bool wino_pick(const ConvArgs& a, const ConvShape& s, int* MT_out) {
     if (MT == 64 && tiles * (a.CoutPad / 64) < 384) MT = 32;
     // 32 couts per workgroup amortise the input transform poorly: with few input channels (padded to
     // chunks of 8, no partial-chunk shortcut here) the direct LDS-DMA kernel is the faster one (measured)
-    if (MT == 32 && a.Cin < 40) return false;
+    static const int min_cin = getenv("VR_WINO_MINCIN") ? atoi(getenv("VR_WINO_MINCIN")) : 24;
+    if (MT == 32 && a.Cin < min_cin) return false;
     *MT_out = MT;
     return true;
 }
