@@ -35,8 +35,10 @@ BWD_CASES = [
     (2, 8, 16, 32, 32, 3, 1, 1, 1, 0, 0, 1.0),
     (1, 40, 24, 64, 64, 3, 1, 1, 1, 0, 1, 0.0),
     (2, 17, 20, 16, 48, 3, 1, 1, 1, 0, 1, 0.01),     # TW=16 tiles, odd Cin, Cout=48
-    (2, 16, 32, 64, 32, 3, 2, 1, 1, 0, 1, 0.01),     # stride 2 (zero-insertion dgrad)
-    (1, 33, 32, 32, 96, 3, 2, 1, 1, 0, 1, 0.01),
+    (2, 16, 32, 64, 32, 3, 2, 1, 1, 0, 1, 0.01),     # stride 2 (parity-class dgrad: 4 tap-masked convs over dz)
+    (1, 24, 18, 128, 40, 3, 2, 1, 1, 0, 1, 0.0),     # stride 2, Cin not a multiple of 8, Cout = 40
+    (2, 8, 15, 72, 64, 3, 2, 1, 1, 0, 0, 1.0),       # stride 2, odd H, W/2 not a multiple of 32
+    (1, 33, 32, 32, 96, 3, 2, 1, 1, 0, 1, 0.01),     # stride 2, 16-wide output (zero-insertion dgrad)
     (2, 32, 32, 16, 32, 3, 1, 4, 2, 0, 1, 0.0),      # dilated
     (1, 64, 32, 16, 64, 3, 1, 12, 6, 0, 1, 0.0),
     (2, 40, 16, 32, 8, 1, 1, 1, 1, 0, 1, 0.0),       # 1x1

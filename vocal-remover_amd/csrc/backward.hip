@@ -397,6 +397,35 @@ __global__ void flip_transpose_kernel(const FlipDesc* descs) {
         d.wt[((long long)co * d.KK + (d.KK - 1 - tap)) * d.CinPad + ci] = d.w[((long long)ci * d.KK + tap) * d.CoutPad + co];
     }
 }
+// Parity-class weights of a stride-2 3x3 conv's data gradient (see ConvArgs::tapmask): for output parity
+// (ph, pw) the gradient is a stride-1 conv over dz whose tap t = (th, tw) (input offset th-1, tw-1) carries the
+// forward weight w[.][.][kh][kw]:   parity 0: th = 1 <- k = 1;   parity 1: th = 1 <- k = 2, th = 2 <- k = 0.
+//   w  [Cin][9][CoutPad] (forward layout)   ->   wc [4][Cout][9][CinPad]  (dz channel, tap, input channel)
+__global__ void s2_class_weights_kernel(const float* __restrict__ w, float* __restrict__ wc, int Cin, int Cout, int CoutPad,
+                                        int CinPad) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long per = (long long)Cout * 9 * CinPad;
+    if (gid >= 4 * per) return;
+    const int cls = (int)(gid / per);
+    long long r = gid - cls * per;
+    const int ci = (int)(r % CinPad); r /= CinPad;
+    const int t = (int)(r % 9);
+    const int co = (int)(r / 9);
+    const int ph = cls >> 1, pw = cls & 1, th = t / 3, tw = t % 3;
+    const int kh = ph == 0 ? (th == 1 ? 1 : -1) : (th == 1 ? 2 : (th == 2 ? 0 : -1));
+    const int kw = pw == 0 ? (tw == 1 ? 1 : -1) : (tw == 1 ? 2 : (tw == 2 ? 0 : -1));
+    float v = 0.f;
+    if (kh >= 0 && kw >= 0 && ci < Cin) v = w[((long long)ci * 9 + kh * 3 + kw) * CoutPad + co];
+    wc[gid] = v;
+}
+
+void launch_s2_class_weights(const float* w, float* wc, int Cin, int Cout, int CoutPad, int CinPad, hipStream_t st) {
+    const long long n = 4LL * Cout * 9 * CinPad;
+    hipLaunchKernelGGL(s2_class_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, wc, Cin, Cout, CoutPad,
+                       CinPad);
+    VR_HIP(hipGetLastError());
+}
+
 void launch_flip_transpose(const FlipDesc* d_descs, int n, hipStream_t st) {
     hipLaunchKernelGGL(flip_transpose_kernel, dim3(64, n), dim3(256), 0, st, d_descs);
     VR_HIP(hipGetLastError());

@@ -54,7 +54,7 @@ struct DmaCfg {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <int KS, int S, int DH, int DW, int MT, int TH, int TW, int CK>
+template <int KS, int S, int DH, int DW, int MT, int TH, int TW, int CK, bool TM = false>
 __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
     using Cfg = DmaCfg<KS, S, DH, DW, MT, TH, TW, CK>;
     constexpr int KK = Cfg::KK, WM = Cfg::WM, WN = Cfg::WN, TWq = Cfg::TWq, TWn = Cfg::TWn, CSX = Cfg::CSX,
@@ -169,7 +169,27 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
         if (k + 1 < nchunk && a.dbg != 1) issue_chunk(k + 1);     // buffer (k+1)&1 was released by the last barrier
         const float* Xs = smem + (k & 1) * Cfg::BUF;
         const float* Ws = Xs + Cfg::XS;
-        if (a.dbg != 2) {
+        if constexpr (TM) {
+            // tap-masked form (parity class of a stride-2 data gradient): only the live taps are multiplied
+#pragma unroll
+            for (int tap = 0; tap < KK; ++tap) {
+                if (!((a.tapmask >> tap) & 1)) continue;                 // wave-uniform
+                const int toff = (tap / KS) * DH * TWq + (tap % KS) * DW;
+#pragma unroll
+                for (int kk = 0; kk < CK / 2; ++kk) {
+                    float av[WM], bv[WN];
+#pragma unroll
+                    for (int mi = 0; mi < WM; ++mi) av[mi] = Ws[(tap * CK + 2 * kk) * MT + aoff + mi * 32];
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni) bv[ni] = Xs[2 * kk * CSX + toff + boff[ni]];
+#pragma unroll
+                    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < WN; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+                }
+            }
+        } else if (a.dbg != 2) {
             float av[WM], bv[WN];
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi) av[mi] = Ws[aoff + mi * 32];
@@ -211,6 +231,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
         if (a.dbg != 2) {
 #pragma unroll
             for (int tap = 0; tap < KK; ++tap) {
+                if (TM && !((a.tapmask >> tap) & 1)) continue;
                 const int toff = (tap / KS) * DH * TWq + (tap % KS) * DW;
                 for (int kk = 0; kk < npair; ++kk) {
                     float av[WM], bv[WN];
@@ -238,7 +259,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
             const int pix = (wave * WN + ni) * 32 + l31;
             const int ho = h0 + pix / TW, wo = w0 + pix % TW;
             okn[ni] = ho < a.Hout && wo < a.Wout && a.dst[0].p != nullptr;
-            offn[ni] = (long long)ho * a.dst[0].sH + wo;
+            offn[ni] = (long long)ho * a.dst[0].sH + ((long long)wo << a.dst[0].wshift);
         }
         float* dbase = a.dst[0].p + (long long)n * a.dst[0].sN;
         const int dacc = a.dst[0].accumulate;
@@ -281,6 +302,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
             const long long dC = seg == 0 ? a.dst[0].sC : (seg == 1 ? a.dst[1].sC : a.dst[2].sC);
             const long long dH = seg == 0 ? a.dst[0].sH : (seg == 1 ? a.dst[1].sH : a.dst[2].sH);
             const int dacc = seg == 0 ? a.dst[0].accumulate : (seg == 1 ? a.dst[1].accumulate : a.dst[2].accumulate);
+            const int dws = seg == 0 ? a.dst[0].wshift : (seg == 1 ? a.dst[1].wshift : a.dst[2].wshift);
 #pragma unroll
             for (int ni = 0; ni < WN; ++ni) {
                 const int pix = (wave * WN + ni) * 32 + l31;
@@ -288,7 +310,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
                 const float v = acc[mi][ni][r] + b;
                 acc[mi][ni][r] = v;
                 if (co < a.Cout && ho < a.Hout && wo < a.Wout && dp) {
-                    float* q = dp + (long long)n * dN + (long long)cod * dC + (long long)ho * dH + wo;
+                    float* q = dp + (long long)n * dN + (long long)cod * dC + (long long)ho * dH + ((long long)wo << dws);
                     const float y = act_apply(fmaf(v, esc, esh), eslope);
                     *q = dacc ? *q + y : y;
                 }
@@ -345,10 +367,10 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------------
-template <int KS, int S, int DH, int DW, int MT, int TH, int TW, int CK>
+template <int KS, int S, int DH, int DW, int MT, int TH, int TW, int CK, bool TM = false>
 static void dma_launch(const ConvArgs& a, hipStream_t st) {
     using Cfg = DmaCfg<KS, S, DH, DW, MT, TH, TW, CK>;
-    auto kern = conv_dma_kernel<KS, S, DH, DW, MT, TH, TW, CK>;
+    auto kern = conv_dma_kernel<KS, S, DH, DW, MT, TH, TW, CK, TM>;
     static bool attr_set = false;
     if (!attr_set) {
         VR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -385,6 +407,7 @@ bool dma_pick(const ConvArgs& a, const ConvShape& s, DmaTile* t) {
         if ((long long)c.H * (c.sH > 0 ? c.sH : 1) * 4 >= 0x7FFFFFF0LL) return false;
     }
     if ((long long)a.Cin * s.KS * s.KS * a.CoutPad * 4 >= 0x7FFFFFF0LL) return false;
+    if (a.tapmask && (a.Wout < 32 || dil || s.KS != 3 || s.stride != 1)) return false;
     if (a.Wout < 32 || dil) {
         // 1/16-resolution layers: 16x16 pixel tiles, 32 couts per workgroup (the grids are small)
         t->TW = 16; t->TH = 16; t->MT = 32;
@@ -403,6 +426,11 @@ bool dma_pick(const ConvArgs& a, const ConvShape& s, DmaTile* t) {
     return true;
 }
 
+bool conv_dma_eligible(const ConvArgs& a, const ConvShape& s) {
+    DmaTile t;
+    return dma_pick(a, s, &t);
+}
+
 void dma_fill_tiling(ConvArgs& a, const DmaTile& t) {
     a.tiles_w = (a.Wout + t.TW - 1) / t.TW;
     a.tiles_h = (a.Hout + t.TH - 1) / t.TH;
@@ -419,6 +447,11 @@ void dma_launch_conv(const ConvArgs& a, const ConvShape& s, const DmaTile& t, hi
         else if (s.dil_h == 4) dma_launch<3, 1, 4, 2, 32, 16, 16, 4>(a, st);
         else if (s.dil_h == 8) dma_launch<3, 1, 8, 4, 32, 16, 16, 4>(a, st);
         else dma_launch<3, 1, 12, 6, 32, 16, 16, 4>(a, st);
+    } else if (s.KS == 3 && s.stride == 1 && a.tapmask) {
+        if (MT == 128) dma_launch<3, 1, 1, 1, 128, 8, 32, 4, true>(a, st);
+        else if (MT == 64) dma_launch<3, 1, 1, 1, 64, 8, 32, 4, true>(a, st);
+        else if (TH == 16) dma_launch<3, 1, 1, 1, 32, 16, 32, 4, true>(a, st);
+        else dma_launch<3, 1, 1, 1, 32, 8, 32, 4, true>(a, st);
     } else if (s.KS == 3 && s.stride == 1) {
         static const int ck4 = getenv("VR_DMA_CK4") ? atoi(getenv("VR_DMA_CK4")) : 7;   // tuning experiment
         if (MT == 128) dma_launch<3, 1, 1, 1, 128, 8, 32, 4>(a, st);

@@ -404,6 +404,7 @@ double launch_conv(const ConvArgs& a_in, const ConvShape& s, hipStream_t st) {
             dma_launch_conv(a, s, dt, st);
             return 2.0 * a.N * (double)a.Hout * a.Wout * (double)a.Cout * a.Cin * s.KS * s.KS;
         }
+        VR_CHECK(a.tapmask == 0, -2, "a tap-masked conv needs the LDS-DMA kernel (conv_dma_eligible)");
         if (ws_pick(a, s, &wmt, &wth)) {
             VR_CHECK(a.nsrc >= 1 && a.nsrc <= 3, -2, "conv takes 1..3 sources");
             ws_fill_tiling(a, wmt, wth);

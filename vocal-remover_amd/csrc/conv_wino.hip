@@ -357,12 +357,13 @@ static void wino_launch(const ConvArgs& a, hipStream_t st) {
 // transformed weights available).
 bool wino_pick(const ConvArgs& a, const ConvShape& s, int* MT_out) {
     static const int enabled = getenv("VR_CONV_WINO") ? atoi(getenv("VR_CONV_WINO")) : 1;
-    if (!enabled || !a.wino) return false;
+    if (!enabled || !a.wino || a.tapmask) return false;
     if (!(s.KS == 3 && s.stride == 1 && s.dil_h == 1 && s.dil_w == 1)) return false;
     if (a.pad_h != 1 || a.pad_w != 1 || a.Wout < 32 || (a.Win & 3)) return false;
     for (int i = 0; i < a.nsrc; ++i) {
         const ConvSrc& c = a.src[i];
         if (c.aff0 || c.aff1 || c.post || c.up || c.zins || c.slope != 1.f || c.W != a.Win) return false;
+        if (i < 3 && a.dst[i].wshift) return false;
         if ((long long)c.H * (c.sH > 0 ? c.sH : 1) * 4 >= 0x7FFFFFF0LL) return false;
     }
     if ((long long)a.Cin * 16 * a.CoutPad * 4 >= 0x7FFFFFF0LL) return false;

@@ -47,6 +47,7 @@ void launch_materialize(const Tensor& x, float* out, hipStream_t st);
 struct AugDesc { float coef, coef_mix, lam; int flags; };
 void launch_augment(const float2* X, const float2* Y, const float2* Xi, const float2* Yi, const AugDesc* desc, const float* rw,
                     int B, int T, int bins, float* Xmag, float* Ymag, hipStream_t st);
+void launch_s2_class_weights(const float* w, float* wc, int Cin, int Cout, int CoutPad, int CinPad, hipStream_t st);
 void launch_wino_weights(const float* w, float* u, int Cin, int CoutPad, hipStream_t st);   // U = G g G^T
 void launch_upsample2x(const Tensor& x, float* out, hipStream_t st);   // dense [N][C][2H][2W], activated
 

@@ -214,6 +214,9 @@ private:
     float* wt_arena = nullptr; size_t wt_floats = 0;     // flipped/transposed conv weights for dgrad
     FlipDesc* d_flip = nullptr; int n_flip = 0;
     std::map<const Param*, float*> wt_of;
+    float* s2w_arena = nullptr;                          // parity-class weights of the stride-2 convs' data gradients
+    std::map<const Param*, float*> s2w_of;
+    std::vector<Conv*> s2_list;
     long long adam_step = 0;
     float* grad_of(const Param* p) { return p->grad_override ? p->grad_override : g_arena + (p->dev - p_arena); }
 public:

@@ -52,6 +52,17 @@ void Model::ensure_train_state() {
         wt_of[L.w] = wt_arena + sl.second;
         descs.push_back(FlipDesc{L.w->dev, wt_arena + sl.second, L.Cin, L.Cout, L.KS * L.KS, round_up32(L.Cin), L.CoutPad});
     }
+    {   // stride-2 3x3 convs: four parity-class weight tensors each (refreshed per step next to the flip)
+        size_t tot = 0;
+        for_each_conv([&](Conv& L) {
+            if (L.KS == 3 && L.stride == 2 && L.dh == 1 && L.dw == 1) { s2_list.push_back(&L); tot += (size_t)4 * L.Cout * 9 * round_up32(L.Cin); }
+        });
+        if (tot) {
+            VR_HIP(hipMalloc(&s2w_arena, tot * sizeof(float)));
+            size_t o = 0;
+            for (Conv* L : s2_list) { s2w_of[L->w] = s2w_arena + o; o += (size_t)4 * L->Cout * 9 * round_up32(L->Cin); }
+        }
+    }
     n_flip = (int)descs.size();
     VR_HIP(hipMalloc(&d_flip, descs.size() * sizeof(FlipDesc)));
     VR_HIP(hipMemcpy(d_flip, descs.data(), descs.size() * sizeof(FlipDesc), hipMemcpyHostToDevice));
@@ -172,6 +183,43 @@ void Model::bwd_conv(TapeRec& r) {
     if (r.srcs.size() == 1) d.d1 = d.d2 = 1 << 30;
     if (r.srcs.size() == 2) d.d2 = 1 << 30;
     if (dry) return;
+    // Stride-2 3x3: four parity-class stride-1 convs over dz (9 tap evaluations) instead of one conv over the
+    // zero-inserted gradient (36), when the LDS-DMA kernel covers the shape.
+    {
+        static const bool s2_classes = !getenv("VR_NO_S2_CLASSES");
+        auto it = s2w_of.find(L.w);
+        bool ok = s2_classes && L.stride == 2 && L.KS == 3 && it != s2w_of.end() && posts.empty() && !r.batch_as_h;
+        if (ok) {
+            ConvArgs c = d;
+            c.src[0].zins = 0;
+            c.Hin = out.H; c.Win = out.W;
+            const ConvShape cshp{3, 1, 1, 1};
+            const size_t cls_stride = (size_t)L.Cout * 9 * round_up32(L.Cin);
+            const int masks[2] = {1 << 1, (1 << 1) | (1 << 2)};          // live taps along one axis: parity 0 / 1
+            for (int cls = 0; cls < 4 && ok; ++cls) {
+                const int ph = cls >> 1, pw = cls & 1;
+                ConvArgs k = c;
+                k.Hout = (f.Hin - ph + 1) / 2; k.Wout = (f.Win - pw + 1) / 2;
+                k.w = it->second + cls * cls_stride;
+                k.wino = nullptr;
+                int tm = 0;
+                for (int th = 0; th < 3; ++th)
+                    for (int tw = 0; tw < 3; ++tw)
+                        if (((masks[ph] >> th) & 1) && ((masks[pw] >> tw) & 1)) tm |= 1 << (th * 3 + tw);
+                k.tapmask = tm;
+                for (int i = 0; i < 3; ++i) {
+                    if (!k.dst[i].p) continue;
+                    k.dst[i].p += (long long)ph * k.dst[i].sH + pw;
+                    k.dst[i].sH *= 2;
+                    k.dst[i].wshift = 1;
+                }
+                if (cls == 0 && !conv_dma_eligible(k, cshp)) { ok = false; break; }
+                if (cls == 0) record_begin(0, 2.0 * N * (double)f.Hout * f.Wout * (double)L.Cout * L.Cin * L.KS * L.KS);
+                launch_conv(k, cshp, stream);
+            }
+            if (ok) { record_end(); return; }
+        }
+    }
     const ConvShape dshp{L.KS, 1, L.dh, L.dw};
     record_begin(0, 2.0 * N * (double)(r.batch_as_h ? 1 : f.Hout) * f.Wout * (double)L.Cout * L.Cin * L.KS * L.KS);
     launch_conv(d, dshp, stream);
@@ -241,6 +289,7 @@ void Model::train_fwd_bwd_api(const float* X, const float* Y, bool on_dev, int B
     // flipped/transposed weights for the data gradients + Winograd-domain copies of both, once per step
     // (before the planning dry run: the kernel choice, hence the partial-statistics layout, depends on them)
     launch_flip_transpose(d_flip, n_flip, stream);
+    for (Conv* L : s2_list) launch_s2_class_weights(L->w->dev, s2w_of[L->w], L->Cin, L->Cout, L->CoutPad, round_up32(L->Cin), stream);
     refresh_wino(true);
     const size_t io_floats = (size_t)B * 2 * output_bin * T;
     const int Hm = max_bin;
@@ -462,6 +511,12 @@ void Model::debug_conv_bwd(const float* x, int N, int Cin, int H, int W, const f
     VR_HIP(hipMalloc(&dfd, sizeof(FlipDesc)));
     VR_HIP(hipMemcpy(dfd, &fd, sizeof(FlipDesc), hipMemcpyHostToDevice));
     launch_flip_transpose(dfd, 1, stream);
+    float* ds2w = nullptr;                    // stride-2 3x3: also exercise the parity-class data gradient
+    if (KS == 3 && stride == 2 && dh == 1 && dw == 1) {
+        VR_HIP(hipMalloc(&ds2w, (size_t)4 * Cout * 9 * CinPad * sizeof(float)));
+        launch_s2_class_weights(dwk, ds2w, Cin, Cout, CoutPad, CinPad, stream);
+        s2w_of[&P] = ds2w;
+    }
     Tensor t;
     t.p = dx; t.g = dgx; t.N = N; t.C = Cin; t.H = H; t.W = W; t.sH = W; t.sC = (long long)H * W; t.sN = t.sC * Cin;
     t.aff0 = daff; t.slope = slope;
@@ -490,6 +545,8 @@ void Model::debug_conv_bwd(const float* x, int N, int Cin, int H, int W, const f
         for (int ci = 0; ci < Cin; ++ci)
             for (int k = 0; k < KK; ++k) dw_out[((size_t)co * Cin + ci) * KK + k] = gk[((size_t)ci * KK + k) * CoutPad + co];
     wt_of.erase(&P);
+    s2w_of.erase(&P);
+    hipFree(ds2w);
     hipFree(dx); hipFree(dgx); hipFree(dwk); hipFree(dwt); hipFree(dgw); hipFree(dzd); hipFree(daff); hipFree(dfd);
 }
 

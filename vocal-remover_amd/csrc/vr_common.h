@@ -80,6 +80,7 @@ struct ConvDst {
     float* p;                  // null: channels of this segment are not stored (e.g. grad of the network input)
     long long sN, sC, sH;
     int accumulate;            // 1: += (gradient accumulation over several consumers)
+    int wshift;                // 1: output column w lands at 2*w (the rows use sH); see ConvArgs::tapmask
 };
 
 struct ConvArgs {
@@ -99,6 +100,10 @@ struct ConvArgs {
     int pad_h, pad_w;
     int tiles_w, tiles_h, npt, nct;
     int dbg;                   // perf experiments only (VR_CONV_DBG): 1 = skip staging, 2 = skip MFMAs
+    int tapmask;               // 0 = all taps; else bit t set = tap t of the 3x3 is used.  The data gradient of a
+                               // stride-2 conv is four stride-1 convs over dz, one per output parity (ph, pw), with
+                               // 1 / 2 / 2 / 4 live taps and outputs interleaved (dst.wshift, doubled row stride):
+                               // 9 tap evaluations instead of the 36 of the zero-insertion form (conv_dma.hip only)
 };
 
 struct ConvShape {             // static description used by the launcher
@@ -124,5 +129,6 @@ size_t wgrad_scratch_floats(const WgradArgs& a, const ConvShape& s);
 double launch_conv(const ConvArgs& a, const ConvShape& s, hipStream_t st);
 size_t conv_part_count(const ConvArgs& a, const ConvShape& s);   // #partials rows (npt)
 void conv_fill_tiling(ConvArgs& a, const ConvShape& s);
+bool conv_dma_eligible(const ConvArgs& a, const ConvShape& s);    // the LDS-DMA kernel covers this launch
 
 }  // namespace vr
