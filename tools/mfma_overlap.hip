@@ -5,8 +5,12 @@
 #include <cstdio>
 #include <cstdlib>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dma4(unsigned lds_base, unsigned voff, i32x4 rsrc) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(lds_base), "v"(voff), "s"(rsrc) : "memory");
+}
 
-// kind: 0 VALU fma chains, 1 LDS writes, 2 global loads (L2-resident), 3 LDS reads
+// kind: 0 VALU fma chains, 1 LDS writes, 2 global loads (L2-resident), 3 LDS reads, 4 LDS-DMA (no VALU in the loop)
 __global__ __launch_bounds__(768) void overlap(const float* __restrict__ in, float* __restrict__ out, int mfma_iters,
                                                int work_iters, int kind) {
     __shared__ float lds[16384];
@@ -50,6 +54,20 @@ __global__ __launch_bounds__(768) void overlap(const float* __restrict__ in, flo
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += v[u];
         }
+    } else if (kind == 4) {
+        const unsigned long long b = (unsigned long long)in;
+        i32x4 r;
+        r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(b & 0xffffffffull));
+        r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((b >> 32) & 0xffffull));
+        r[2] = 1 << 24;
+        r[3] = 0x00020000;
+        const unsigned base = (unsigned)(size_t)lds + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
+        const unsigned vo = (unsigned)((tid - 256) * 4 + (blockIdx.x & 63) * 4096);
+        for (int it = 0; it < work_iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dma4(base + u * 256, vo + u * 32768, r);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         for (int it = 0; it < work_iters; ++it) {
 #pragma unroll
@@ -67,9 +85,9 @@ int main() {
     float* h = (float*)malloc((1 << 22) * 4);
     for (int i = 0; i < (1 << 22); ++i) h[i] = (float)rand() / (float)RAND_MAX - 0.5f;
     (void)hipMemcpy(in, h, (1 << 22) * 4, hipMemcpyHostToDevice);
-    const char* names[4] = {"VALU fma", "LDS write", "global load", "LDS read"};
-    const int witers[4] = {40000, 20000, 3000, 20000};
-    for (int kind = 0; kind < 4; ++kind) {
+    const char* names[5] = {"VALU fma", "LDS write", "global load", "LDS read", "LDS-DMA"};
+    const int witers[5] = {40000, 20000, 3000, 20000, 3000};
+    for (int kind = 0; kind < 5; ++kind) {
         float t[3];
         for (int cfg = 0; cfg < 3; ++cfg) {
             const int mi = cfg == 1 ? 0 : 10000, wi = cfg == 0 ? 0 : witers[kind];
