@@ -241,3 +241,42 @@ def test_training_set_device_pipeline_vs_oracle(vr, small_train, tmp_path):
     assert len(shapes) == len(loader) == 2 and shapes[0] == (4, 2, bins, 48) and shapes[1] == (2, 2, bins, 48)
     x0, y0 = ds[1]
     assert tuple(x0.shape) == (2, bins, 48) and x0.device.type == 'cuda'
+
+
+def test_validation_set_and_lr_scheduler_drop_in(vr, small_train, tmp_path):
+    """§8f rank 3 pieces: VocalRemoverValidationSet (lib/dataset.py:123-140) magnitudes on the device, validate_epoch
+    over a DeviceLoader, and torch's ReduceLROnPlateau driving the native Adam (train.py:220-227,289)."""
+    model, sd = small_train
+    model.load_state_dict(sd)
+    bins, T = N_FFT // 2 + 1, 160
+    rng = np.random.RandomState(3)
+    paths = []
+    for i in range(3):
+        X = (rng.randn(2, bins, T) + 1j * rng.randn(2, bins, T)).astype(np.complex64) * 0.2
+        y = (X * rng.rand(2, bins, T)).astype(np.complex64)
+        p = str(tmp_path / ('patch%d.npz' % i))
+        np.savez(p, X=X, y=y)
+        paths.append((p, X, y))
+    ds = vr.dataset.VocalRemoverValidationSet([p for p, _, _ in paths], model=model)
+    Xm, ym = ds.batch([0, 2])
+    assert float(np.abs(Xm[1].cpu().numpy() - np.abs(paths[2][1])).max()) < 1e-6
+    assert float(np.abs(ym[0].cpu().numpy() - np.abs(paths[0][2])).max()) < 1e-6
+    from vocal_remover_amd import train as vtrain
+    loader = vr.dataset.DeviceLoader(ds, batch_size=2, shuffle=False)
+    val = vtrain.validate_epoch(loader, model, torch.device('cuda:0'))
+    assert np.isfinite(val) and val > 0
+    opt = vtrain.Adam(model.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=0.9, patience=1, threshold=1e-6, min_lr=1e-4)
+    for _ in range(4):
+        sched.step(1.0)                              # no improvement -> lr decays after `patience` epochs
+    assert abs(opt.param_groups[0]['lr'] - 1e-3 * 0.9) < 1e-12 or opt.param_groups[0]['lr'] < 1e-3
+    model.train()
+    X, y = train_step.synth_batch(2, T=64, n_fft=N_FFT, seed=11)
+    model.set_dropout_masks(None)
+    model.zero_grad()
+    model.train_step(X.to('cuda:0'), y.to('cuda:0'), 1)
+    before = model.state_dict()['out.weight'].clone()
+    opt.step()
+    after = model.state_dict()['out.weight']
+    step = float((after - before).abs().max())
+    assert 0 < step <= opt.param_groups[0]['lr'] * 1.001          # |Adam step 1| = lr per element (bias-corrected)

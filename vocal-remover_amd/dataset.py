@@ -145,6 +145,42 @@ class VocalRemoverTrainingSet(object):
         return X_mag[0], y_mag[0]
 
 
+class VocalRemoverValidationSet(object):
+    """lib/dataset.py:123-140: validation patches saved by make_validation_set as .npz with complex X, y of shape
+    [2, bins, cropsize]; `abs` runs on the model's GPU (vr_augment_batch with no augmentation flags)."""
+
+    def __init__(self, patch_list, model=None):
+        self.patch_list = patch_list
+        self.model = model
+
+    def __len__(self):
+        return len(self.patch_list)
+
+    def batch(self, indices):
+        if self.model is None:
+            raise RuntimeError('VocalRemoverValidationSet needs the model (its device computes the magnitudes); no CPU fallback')
+        h = self.model._need_handle()
+        Xs, ys = [], []
+        for i in indices:
+            data = np.load(self.patch_list[i])
+            Xs.append(np.ascontiguousarray(data['X'].astype(np.complex64, copy=False).transpose(2, 0, 1)))   # -> [T, 2, bins]
+            ys.append(np.ascontiguousarray(data['y'].astype(np.complex64, copy=False).transpose(2, 0, 1)))
+        X, y = np.stack(Xs), np.stack(ys)
+        B, T, _, bins = X.shape
+        desc = (_Aug * B)(*[_Aug(1.0, 1.0, 1.0, 0) for _ in range(B)])
+        dev = torch.device('cuda', h.device)
+        X_mag = torch.empty((B, 2, bins, T), dtype=torch.float32, device=dev)
+        y_mag = torch.empty((B, 2, bins, T), dtype=torch.float32, device=dev)
+        native.check(native.lib().vr_augment_batch(h.h, native.np_ptr(X), native.np_ptr(y), None, None,
+                                                   ctypes.cast(desc, ctypes.c_void_p), None, B, T, bins, 0,
+                                                   ctypes.c_void_p(X_mag.data_ptr()), ctypes.c_void_p(y_mag.data_ptr()), 1))
+        return X_mag, y_mag
+
+    def __getitem__(self, idx):
+        X_mag, y_mag = self.batch([idx])
+        return X_mag[0], y_mag[0]
+
+
 class DeviceLoader(object):
     """Iterable stand-in for torch.utils.data.DataLoader(dataset, batch_size, shuffle) (train.py:242-247):
     yields (X_batch, y_batch) device tensors produced by one vr_augment_batch call per batch."""

@@ -26,8 +26,11 @@ class _ParamRef(object):
         self.model = model
 
 
-class Adam(object):
-    """torch.optim.Adam(params, lr) with the reference's defaults, executed by vr_adam_step."""
+class Adam(torch.optim.Optimizer):
+    """torch.optim.Adam(params, lr) with the reference's defaults (train.py:215-218), executed by the fused
+    vr_adam_step over the library's flat parameter / gradient / moment arenas.  It IS a torch Optimizer (one
+    param group, a placeholder tensor), so torch.optim.lr_scheduler.ReduceLROnPlateau (train.py:220-227) drives
+    `param_groups[0]['lr']` exactly as in the reference."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
         if weight_decay != 0:
@@ -36,18 +39,21 @@ class Adam(object):
         if not refs:
             raise ValueError('pass model.parameters() of a vocal_remover_amd CascadedNet')
         self.model = refs[0].model
-        self.param_groups = [{'lr': lr, 'betas': betas, 'eps': eps}]
         self.grad_scale = 1.0
+        self._placeholder = torch.zeros(1, requires_grad=True)
+        super().__init__([self._placeholder], dict(lr=lr, betas=betas, eps=eps))
         self.model.set_option('adam_reset', 1)      # a new optimizer starts without moments, like torch.optim.Adam
 
-    def step(self):
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
         g = self.param_groups[0]
         h = self.model._need_handle()
         native.check(native.lib().vr_adam_step(h.h, float(g['lr']), float(g['betas'][0]), float(g['betas'][1]),
                                                float(g['eps']), float(self.grad_scale)))
         self.model._host_stale = True
+        return loss
 
-    def zero_grad(self):
+    def zero_grad(self, set_to_none=True):
         self.model.zero_grad()
 
 
