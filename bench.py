@@ -93,8 +93,9 @@ def cpu_baseline_infer(sd, frames=1292):
 
 CONV_FAMILY_INFER = ('conv family on v_mfma_f32_32x32x2_f32: conv_wino_kernel<*> (Winograd F(2x2,3x3), the 3x3 stride-1 '
                      'layers) + conv_dma_kernel<*> (direct implicit GEMM: stride-2, dilated, 1x1, thin layers)')
-CONV_FAMILY_TRAIN = ('conv family on v_mfma_f32_32x32x2_f32: conv_ws_kernel<*> / conv_mfma_kernel<*> (forward + '
-                     'data gradient, fused BatchNorm/activation/upsample loader) + wgrad_ws_kernel<*> (weight gradient)')
+CONV_FAMILY_TRAIN = ('conv family on v_mfma_f32_32x32x2_f32: conv_wino_kernel<*> / conv_dma_kernel<*> (forward + data '
+                     'gradients over materialised plain tensors; stride-2 data gradient = 4 tap-masked parity convs) + '
+                     'wgrad_ws_kernel<*> (weight gradient, LDS-DMA loader)')
 
 
 def main():
