@@ -132,7 +132,8 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ dhi, int N, int C,
     const int n = (int)(t / C);
     const int H2 = 2 * H, W2 = 2 * W;
     const float* src = dhi + ((long long)n * C + c) * H2 * W2;
-    int hlo = 2 * i - 3, hhi = 2 * i + 3, wlo = 2 * j - 3, whi = 2 * j + 3;
+    // rows/columns that can touch low-res index i: floor(r*h) in {i-1, i} with r = (H-1)/(2H-1) < 1/2  =>  h in [2i-2, 2i+2]
+    int hlo = 2 * i - 2, hhi = 2 * i + 2, wlo = 2 * j - 2, whi = 2 * j + 2;
     hlo = hlo < 0 ? 0 : hlo; wlo = wlo < 0 ? 0 : wlo;
     hhi = hhi > H2 - 1 ? H2 - 1 : hhi; whi = whi > W2 - 1 ? W2 - 1 : whi;
     float acc = 0.f;
