@@ -132,30 +132,45 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ dhi, int N, int C,
     const int n = (int)(t / C);
     const int H2 = 2 * H, W2 = 2 * W;
     const float* src = dhi + ((long long)n * C + c) * H2 * W2;
-    // rows/columns that can touch low-res index i: floor(r*h) in {i-1, i} with r = (H-1)/(2H-1) < 1/2  =>  h in [2i-2, 2i+2]
-    int hlo = 2 * i - 2, hhi = 2 * i + 2, wlo = 2 * j - 2, whi = 2 * j + 2;
-    hlo = hlo < 0 ? 0 : hlo; wlo = wlo < 0 ? 0 : wlo;
-    hhi = hhi > H2 - 1 ? H2 - 1 : hhi; whi = whi > W2 - 1 ? W2 - 1 : whi;
-    float acc = 0.f;
-    for (int h = hlo; h <= hhi; ++h) {
-        const float h1r = rh * (float)h;
-        const int h1 = (int)h1r;
-        const int h1p = (h1 < H - 1) ? 1 : 0;
-        const float l1 = h1r - (float)h1, l0 = 1.f - l1;
-        float wh = 0.f;
-        if (h1 == i) wh += l0;
-        if (h1 + h1p == i) wh += l1;
-        if (wh == 0.f) continue;
-        for (int w = wlo; w <= whi; ++w) {
+    // rows/columns that can touch low-res index i: floor(r*h) in {i-1, i} with r = (H-1)/(2H-1) < 1/2  =>  h in [2i-2, 2i+2];
+    // the five row weights and five column weights are computed once, then a 5x5 weighted sum
+    float wh[5], ww[5];
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+        const int h = 2 * i - 2 + d;
+        float v = 0.f;
+        if (h >= 0 && h < H2) {
+            const float h1r = rh * (float)h;
+            const int h1 = (int)h1r;
+            const int h1p = (h1 < H - 1) ? 1 : 0;
+            const float l1 = h1r - (float)h1;
+            if (h1 == i) v += 1.f - l1;
+            if (h1 + h1p == i) v += l1;
+        }
+        wh[d] = v;
+        const int w = 2 * j - 2 + d;
+        float u = 0.f;
+        if (w >= 0 && w < W2) {
             const float w1r = rw * (float)w;
             const int w1 = (int)w1r;
             const int w1p = (w1 < W - 1) ? 1 : 0;
-            const float m1 = w1r - (float)w1, m0 = 1.f - m1;
-            float ww = 0.f;
-            if (w1 == j) ww += m0;
-            if (w1 + w1p == j) ww += m1;
-            if (ww != 0.f) acc = fmaf(wh * ww, src[(long long)h * W2 + w], acc);
+            const float m1 = w1r - (float)w1;
+            if (w1 == j) u += 1.f - m1;
+            if (w1 + w1p == j) u += m1;
         }
+        ww[d] = u;
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int dh = 0; dh < 5; ++dh) {
+        if (wh[dh] == 0.f) continue;
+        const int h = 2 * i - 2 + dh;
+        const float* row = src + (long long)h * W2 + 2 * j - 2;
+        float r = 0.f;
+#pragma unroll
+        for (int dw = 0; dw < 5; ++dw)
+            if (ww[dw] != 0.f) r = fmaf(ww[dw], row[dw], r);
+        acc = fmaf(wh[dh], r, acc);
     }
     glo[(long long)n * gN + (long long)c * gC + (long long)i * gH + j] += acc;
 }
