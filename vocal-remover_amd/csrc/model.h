@@ -159,6 +159,7 @@ private:
     Arena ws;                                            // activations workspace
     Arena io;                                            // persistent I/O staging (spec, mask, waves)
     void ensure_ws(size_t bytes);
+    int plan_B = -1, plan_T = -1; bool plan_training = false; size_t plan_peak = 0;    // memo of plan_and_reserve
     void ensure_io(size_t bytes);
 
     std::deque<BN> bns;

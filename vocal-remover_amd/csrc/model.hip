@@ -817,6 +817,12 @@ Tensor Model::run_net(const Tensor& x) {
 }
 
 void Model::plan_and_reserve(int B, int T, size_t extra_bytes) {
+    // the dry run is pure host work (~0.3 ms for the full net): remember its result per (B, T, mode)
+    if (plan_B == B && plan_T == T && plan_training == training && plan_peak > 0) {
+        ensure_ws(plan_peak + extra_bytes + 4096);
+        ws.reset();
+        return;
+    }
     Arena saved = ws;
     ws.dry = true; ws.base = nullptr; ws.off = 0; ws.peak = 0;
     dry = true;
@@ -826,6 +832,7 @@ void Model::plan_and_reserve(int B, int T, size_t extra_bytes) {
     try { run_net(x); } catch (...) { dry = false; ws = saved; throw; }
     dry = false;
     const size_t need = ws.peak + extra_bytes + 4096;
+    plan_B = B; plan_T = T; plan_training = training; plan_peak = ws.peak;
     ws = saved;
     ensure_ws(need);
     ws.reset();
