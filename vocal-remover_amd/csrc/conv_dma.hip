@@ -416,7 +416,8 @@ bool dma_pick(const ConvArgs& a, const ConvShape& s, DmaTile* t) {
     int MT = (a.CoutPad % 128 == 0) ? 128 : ((a.CoutPad % 64 == 0) ? 64 : 32);
     if (s.stride == 2 && MT == 128) MT = 64;
     const long long tiles = (long long)a.N * ((a.Hout + 7) / 8) * ((a.Wout + 31) / 32);
-    while (MT > 32 && tiles * (a.CoutPad / MT) < 768) MT /= 2;
+    static const int minblk = getenv("VR_DMA_MINBLK") ? atoi(getenv("VR_DMA_MINBLK")) : 768;
+    while (MT > 32 && tiles * (a.CoutPad / MT) < minblk) MT /= 2;
     int TH = 8;
     if (MT == 32 && s.stride == 1) {
         const long long tiles16 = (long long)a.N * ((a.Hout + 15) / 16) * ((a.Wout + 31) / 32);

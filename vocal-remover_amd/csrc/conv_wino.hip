@@ -369,7 +369,8 @@ bool wino_pick(const ConvArgs& a, const ConvShape& s, int* MT_out) {
     if ((long long)a.Cin * 16 * a.CoutPad * 4 >= 0x7FFFFFF0LL) return false;
     const long long tiles = (long long)a.N * ((a.Hout + 7) / 8) * ((a.Wout + 31) / 32);
     int MT = (a.CoutPad % 64 == 0) ? 64 : 32;
-    if (MT == 64 && tiles * (a.CoutPad / 64) < 384) MT = 32;
+    static const int min64 = getenv("VR_WINO_MIN64") ? atoi(getenv("VR_WINO_MIN64")) : 384;
+    if (MT == 64 && tiles * (a.CoutPad / 64) < min64) MT = 32;
     // 32 couts per workgroup amortise the input transform poorly: with few input channels (padded to
     // chunks of 8, no partial-chunk shortcut here) the direct LDS-DMA kernel is the faster one (measured)
     static const int min_cin = getenv("VR_WINO_MINCIN") ? atoi(getenv("VR_WINO_MINCIN")) : 24;
