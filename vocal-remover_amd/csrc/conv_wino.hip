@@ -217,6 +217,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
     }
 
     // ---------------- epilogue: gather the 16 frequencies per (cout, tile) through LDS, A^T M A ------------
+    if (a.dbg == 4) return;                                            // (ablation: no epilogue, no stores)
     float* Mx = smem;                                                  // [16][32][MP]
     float* stat = smem + 16 * 32 * MP;                                 // [MT][2] BatchNorm partial sums (training)
     if (a.part && tid < 2 * MT) stat[tid] = 0.f;                       // (ordered by the first pass's barriers)
