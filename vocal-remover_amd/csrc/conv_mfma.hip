@@ -1,7 +1,12 @@
-// Fused convolution for the CascadedNet blocks (lib/layers.py:8-64, 67-105) on gfx950.
+// Conv dispatcher (launch_conv) + the fused-LOADER convolution for the CascadedNet blocks
+// (lib/layers.py:8-64, 67-105) on gfx950.
 //
-// One kernel family covers every conv of the hot path:
-//   3x3 stride 1 (K3), 3x3 stride 2 (K4), 3x3 dilated (K5), 1x1 (K6) -- SURVEY.md section 2.
+// launch_conv picks, in this order:  conv_wino.hip (Winograd F(2x2,3x3), plain inputs, 3x3 stride 1)  ->
+// conv_dma.hip (direct implicit GEMM, plain inputs by LDS-DMA)  ->  conv_ws.hip / the kernel below (inputs that
+// still carry a pending BatchNorm affine / activation / dropout / x2 upsample / zero insertion).  Eval mode and
+// the materialised training path only produce plain inputs, so the kernel in this file is what remains for
+// non-materialised training (VR_NO_TRAIN_MAT), 16-wide stride-2 data gradients and the unit-test hook.
+//
 // Structure: LDS-staged implicit GEMM.  A workgroup (4 waves) owns MT output channels x a
 // TH x TW tile of output pixels of one image and walks the input channels in chunks of CK:
 //   stage   the haloed input tile  Xs[CK][TH_in][TWp]   (global -> regs -> transform -> LDS)
@@ -10,14 +15,12 @@
 //           A[i=cout][k=ci pair] from Ws, B[k][j=pixel] from Xs, accumulators stay in registers.
 // The staging step is where the fusion happens (vr_common.h): virtual channel-concat of up to
 // three sources, the decoder's bilinear x2 upsample (align_corners=True), the producer's
-// BatchNorm affine and ReLU/LeakyReLU, and conv zero padding -- so neither the upsampled tensor
-// nor the concatenated tensor nor a normalised copy ever exists in HBM.
-// The epilogue stores the RAW conv output (+ optional bias) and, in training mode, per-block
-// (sum, sumsq) partials per output channel for the BatchNorm batch statistics.
+// BatchNorm affine and ReLU/LeakyReLU, and conv zero padding.
+// The epilogue stores the conv output (+ optional bias; eval: folded BatchNorm + activation) and, in
+// training mode, per-block (sum, sumsq) partials per output channel for the BatchNorm batch statistics.
 //
-// fp32 MFMA runs at the fp32 vector rate (157 TFLOP/s peak) but reaches it with one LDS read
-// per operand per 64-cycle instruction, which is what makes a >100 TFLOP/s conv reachable; the
-// VALU stays free for the staging transforms.
+// Measured later in the round (tools/mfma_overlap.hip): the loader's VALU work is NOT hidden behind the
+// fp32 MFMAs on gfx950 -- the reason the plain-input kernels exist.
 #include <cstdlib>
 
 #include "conv_stage.h"

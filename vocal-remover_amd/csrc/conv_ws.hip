@@ -1,15 +1,15 @@
-// Warp-specialised 3x3 / 1x1 stride-1 convolution (the layers that hold ~85 % of the FLOPs).
+// Warp-specialised form of the fused-loader convolution (3x3 stride 1/2 and 1x1, >= 32 output columns) for
+// inputs that still carry a pending BatchNorm affine / activation / upsample (see conv_mfma.hip for when
+// that happens; plain inputs take conv_wino.hip / conv_dma.hip).
 //
-// Measured on MI355X (profiles/README.md): the pure "LDS operands -> v_mfma_f32_32x32x2_f32" loop of
-// conv_mfma.hip sustains ~120 TFLOP/s, but when the same waves also run the fused loader
-// (BatchNorm affine + activation + bilinear upsample + concat + padding) the matrix pipe idles ~45 %
-// of the time: a wave issues in order, so its loader instructions and its MFMAs never overlap.
-// Here a 512-thread workgroup splits the roles:
-//   waves 0-3  consumers: nothing but LDS operand reads + MFMAs (+ the epilogue)
-//   waves 4-7  producers: prefetch raw tiles of chunk k+2 into registers, transform chunk k+1 into
-//              the other LDS buffer (same table-driven loader as conv_mfma.hip)
-// with ONE workgroup barrier per input-channel chunk.  Producer work hides entirely under the MFMA
-// phase as long as it is shorter (it is: ~3-4k cycles vs 9-18k).
+// A wave issues in order, so a wave that runs the loader and the MFMAs never overlaps the two.  Here the
+// workgroup splits the roles:
+//   waves 0-3   consumers: nothing but LDS operand reads + MFMAs (+ the epilogue)
+//   waves 4-..  producers (8-12): prefetch raw tiles of chunk k+2 into registers, transform chunk k+1 into
+//               the other LDS buffer (same table-driven loader as conv_mfma.hip)
+// with ONE workgroup barrier per input-channel chunk.  This hides the loader's memory LATENCY; its VALU
+// instructions still take SIMD time away from the MFMAs (measured: tools/mfma_overlap.hip), which caps
+// this kernel at 88-100 TFLOP/s on the big layers (profiles/README.md).
 #include <cstdlib>
 
 #include "conv_stage.h"
