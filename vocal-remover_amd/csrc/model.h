@@ -147,10 +147,9 @@ public:
     // eval mode, second lane: the crops of a batch are independent, so separate() runs the two halves
     // of the batch as two concurrent chains (own streams, own workspace); the tail of one chain's
     // kernels and its memory-bound kernels (upsample, LSTM, copies) overlap the other chain's convs.
-    hipStream_t stream_b = nullptr, side_b = nullptr;
-    hipEvent_t evb_fork = nullptr, evb_join = nullptr, evb_start = nullptr, evb_done = nullptr;
-    Arena ws_b;
-    void swap_lane();
+    struct Lane { hipStream_t main = nullptr, side = nullptr; hipEvent_t fork = nullptr, join = nullptr, start = nullptr, done = nullptr; Arena ws; };
+    std::vector<Lane> lanes;                             // the additional lanes (VR_LANES - 1, default 1)
+    void swap_lane(int i);
 
 private:
     // arenas

@@ -132,12 +132,17 @@ Model::Model(int device_, int n_fft_, int hop_, int nout_, int nout_lstm_)
         VR_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         VR_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
         if (!getenv("VR_NO_SPLIT_BATCH")) {
-            VR_HIP(hipStreamCreateWithFlags(&stream_b, hipStreamNonBlocking));
-            VR_HIP(hipStreamCreateWithFlags(&side_b, hipStreamNonBlocking));
-            VR_HIP(hipEventCreateWithFlags(&evb_fork, hipEventDisableTiming));
-            VR_HIP(hipEventCreateWithFlags(&evb_join, hipEventDisableTiming));
-            VR_HIP(hipEventCreateWithFlags(&evb_start, hipEventDisableTiming));
-            VR_HIP(hipEventCreateWithFlags(&evb_done, hipEventDisableTiming));
+            int k = getenv("VR_LANES") ? atoi(getenv("VR_LANES")) : 2;
+            k = k < 1 ? 1 : (k > 4 ? 4 : k);
+            lanes.resize(k - 1);
+            for (Lane& l : lanes) {
+                VR_HIP(hipStreamCreateWithFlags(&l.main, hipStreamNonBlocking));
+                VR_HIP(hipStreamCreateWithFlags(&l.side, hipStreamNonBlocking));
+                VR_HIP(hipEventCreateWithFlags(&l.fork, hipEventDisableTiming));
+                VR_HIP(hipEventCreateWithFlags(&l.join, hipEventDisableTiming));
+                VR_HIP(hipEventCreateWithFlags(&l.start, hipEventDisableTiming));
+                VR_HIP(hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
+            }
         }
     }
     const int nin = 2;
@@ -234,11 +239,11 @@ Model::~Model() {
     hipFree(ws.base); hipFree(io.base); hipFree(gs.base); hipFree(wino_arena); hipFree(winot_arena); hipFree(aug_buf);
     hipFree(g_arena); hipFree(m_arena); hipFree(v_arena); hipFree(wt_arena); hipFree(d_flip); hipFree(dropout_buf);
     hipFree(plan.twiddle); hipFree(plan.window);
-    if (stream_b) {
-        hipStreamSynchronize(stream_b); hipStreamSynchronize(side_b);
-        hipStreamDestroy(stream_b); hipStreamDestroy(side_b);
-        hipEventDestroy(evb_fork); hipEventDestroy(evb_join); hipEventDestroy(evb_start); hipEventDestroy(evb_done);
-        hipFree(ws_b.base);
+    for (Lane& l : lanes) {
+        hipStreamSynchronize(l.main); hipStreamSynchronize(l.side);
+        hipStreamDestroy(l.main); hipStreamDestroy(l.side);
+        hipEventDestroy(l.fork); hipEventDestroy(l.join); hipEventDestroy(l.start); hipEventDestroy(l.done);
+        hipFree(l.ws.base);
     }
     if (side_stream) { hipStreamSynchronize(side_stream); hipStreamDestroy(side_stream); hipEventDestroy(ev_fork); hipEventDestroy(ev_join); }
     if (stream) hipStreamDestroy(stream);
@@ -368,12 +373,13 @@ void Model::ensure_ws(size_t bytes) {
 
 // Exchange lane A (stream, side_stream, ws) with lane B: run_net() and the launch helpers only know the
 // member names, so the second half-batch is enqueued by swapping, running, swapping back.
-void Model::swap_lane() {
-    std::swap(stream, stream_b);
-    std::swap(side_stream, side_b);
-    std::swap(ev_fork, evb_fork);
-    std::swap(ev_join, evb_join);
-    std::swap(ws, ws_b);
+void Model::swap_lane(int i) {
+    Lane& l = lanes[i];
+    std::swap(stream, l.main);
+    std::swap(side_stream, l.side);
+    std::swap(ev_fork, l.fork);
+    std::swap(ev_join, l.join);
+    std::swap(ws, l.ws);
 }
 
 void Model::ensure_io(size_t bytes) {
@@ -1057,27 +1063,36 @@ void Model::separate_api(const float* spec, bool on_dev, int T, int tta, int bat
         };
         for (int i = 0; i < patches; i += bs) {
             const int nb = std::min(bs, patches - i);
-            const bool split = stream_b != nullptr && !profiling && nb >= 2;
-            if (!split) {
+            const int K = std::min((int)lanes.size() + 1, nb);
+            if (K < 2 || profiling) {
                 run_crops(i, nb);
                 continue;
             }
-            const int na = (nb + 1) / 2;
-            if (ws_b.cap < ws.cap) {                     // lane B's workspace: same plan, same size
+            // crops [i, i+nb) in K contiguous parts; part 0 on the handle's own streams, part j on lane j-1
+            for (Lane& l : lanes) {
+                if (l.ws.cap >= ws.cap) continue;            // every lane plans for the same (bs, cropsize)
                 VR_HIP(hipDeviceSynchronize());
-                if (ws_b.base) VR_HIP(hipFree(ws_b.base));
-                ws_b.base = nullptr; ws_b.cap = 0;
-                VR_HIP(hipMalloc(reinterpret_cast<void**>(&ws_b.base), ws.cap));
-                ws_b.cap = ws.cap;
+                if (l.ws.base) VR_HIP(hipFree(l.ws.base));
+                l.ws.base = nullptr; l.ws.cap = 0;
+                VR_HIP(hipMalloc(reinterpret_cast<void**>(&l.ws.base), ws.cap));
+                l.ws.cap = ws.cap;
             }
-            VR_HIP(hipEventRecord(evb_start, stream));   // `mag` is ready at this point of lane A's stream
-            VR_HIP(hipStreamWaitEvent(stream_b, evb_start, 0));
-            run_crops(i, na);
-            swap_lane();
-            try { run_crops(i + na, nb - na); } catch (...) { swap_lane(); throw; }
-            VR_HIP(hipEventRecord(evb_done, stream));
-            swap_lane();
-            VR_HIP(hipStreamWaitEvent(stream, evb_done, 0));
+            const int per = (nb + K - 1) / K;
+            for (int j = 1; j < K; ++j) {                    // `mag` is ready at this point of the main stream
+                VR_HIP(hipEventRecord(lanes[j - 1].start, stream));
+                VR_HIP(hipStreamWaitEvent(lanes[j - 1].main, lanes[j - 1].start, 0));
+            }
+            run_crops(i, std::min(per, nb));
+            for (int j = 1; j < K; ++j) {
+                const int first = j * per, count = std::min(per, nb - first);
+                if (count <= 0) break;
+                swap_lane(j - 1);
+                try { run_crops(i + first, count); } catch (...) { swap_lane(j - 1); throw; }
+                hipEvent_t done = lanes[j - 1].done;
+                VR_HIP(hipEventRecord(done, stream));
+                swap_lane(j - 1);
+                VR_HIP(hipStreamWaitEvent(stream, done, 0));
+            }
         }
     }
     const float* wgt = nullptr;
