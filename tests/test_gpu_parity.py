@@ -208,6 +208,20 @@ def test_predict_variants_small_net(small):
     assert torch.equal(got_f[:, :, -1], got_f[:, :, -2])
 
 
+@pytest.mark.parametrize('B,T', [(1, 16), (3, 32), (2, 80), (1, 272), (5, 160)])
+def test_forward_shape_sweep_small_net(small, B, T):
+    """Every valid frame count (multiples of 16) and batch size: at the small ones the deep levels are 1-8
+    columns wide, so the dispatcher leaves the LDS-DMA / Winograd kernels (16-byte pieces need W % 4 == 0) for
+    the fused-loader ones and the odd-width upsample -- same results either way."""
+    model, sd, n_fft = small
+    x = torch.rand(B, 2, n_fft // 2 + 1, T, generator=torch.Generator().manual_seed(100 + T))
+    with torch.no_grad():
+        want = cascaded_net.forward(x, sd, n_fft=n_fft)
+    got = model(x.to('cuda:0')).cpu()
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) < 1e-4
+
+
 def test_reference_error_behaviour(small):
     model, sd, n_fft = small
     with pytest.raises(ValueError):        # crop_center ValueError (frames not a multiple of 16)
