@@ -280,3 +280,23 @@ def test_validation_set_and_lr_scheduler_drop_in(vr, small_train, tmp_path):
     after = model.state_dict()['out.weight']
     step = float((after - before).abs().max())
     assert 0 < step <= opt.param_groups[0]['lr'] * 1.001          # |Adam step 1| = lr per element (bias-corrected)
+
+
+@pytest.mark.parametrize('B,T', [(1, 32), (3, 80), (2, 272)])
+def test_train_step_shape_sweep_loss_and_a_gradient(small_train, B, T):
+    """Other batch sizes / frame counts than the main parity test (deep levels 2..17 columns wide: mixed kernel
+    dispatch, odd-width upsample backward): loss and one well-conditioned gradient vs the fp32 CPU oracle."""
+    model, sd = small_train
+    model.load_state_dict(sd)
+    model.train()
+    model.set_option('train_winograd', 1)
+    model.set_dropout_masks(None)
+    X, y = train_step.synth_batch(B, T=T, n_fft=N_FFT, seed=40 + T)
+    sd32 = weights.clone_state_dict(sd)
+    loss32, g32 = train_step.loss_and_grads(sd32, X, y, n_fft=N_FFT, dropout=None)
+    model.zero_grad()
+    loss = model.train_step(X.to('cuda:0'), y.to('cuda:0'), 1)
+    assert abs(loss - float(loss32)) < 1e-5, (loss, float(loss32))
+    g = model.grads(keys={'out.weight', 'stg3_full_band_net.dec1.conv1.conv.0.weight'})
+    for k in g:
+        assert _rel(g[k], g32[k]) < 5e-2, (k, _rel(g[k], g32[k]))
