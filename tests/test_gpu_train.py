@@ -102,8 +102,7 @@ def oracle_step(small_train):
 def test_train_step_vs_fp64_oracle(small_train, oracle_step, winograd):
     """winograd=0: direct MFMA kernels only.  winograd=1 (the library default): the 3x3 stride-1 forward and
     data-gradient convs use Winograd F(2x2,3x3), whose fp32 rounding differs by ~1e-6 per conv; the error
-    DISTRIBUTION must stay that of the fp32 CPU oracle (median / p95 bars unchanged), only the bar for
-    cancellation-dominated tiny tensors (a 1-element BatchNorm bias) is wider."""
+    DISTRIBUTION must stay that of the fp32 CPU oracle (same per-tensor, median and p95 bars in both modes)."""
     model, sd = small_train
     X, y, masks, sd64, loss64, g64, g32 = oracle_step
     model.load_state_dict(sd)
@@ -126,7 +125,10 @@ def test_train_step_vs_fp64_oracle(small_train, oracle_step, winograd):
         e_gpu, e_cpu = _rel(grads[k], g64[k]), _rel(g32[k], g64[k])
         report.append((e_gpu, e_cpu, k))
         # tiny tensors (a 1-element BatchNorm bias) have no averaging: their relative error is luck
-        tiny = max(8 * e_cpu, 0.5) if winograd else max(5 * e_cpu, 0.15)
+        # a 1-element BatchNorm bias is one cancellation-dominated sum: any benign change of the fp32 summation
+        # order upstream (Winograd, the LSTM's four FMA chains) moves it by tens of percent -- measured 0.06 (CPU
+        # fp32 oracle), 0.15-0.35 (GPU variants) against fp64 -- so tiny tensors only get a sanity bar
+        tiny = max(8 * e_cpu, 0.5)
         tol = max(5 * e_cpu, 3e-2) if g64[k].numel() >= 16 else tiny
         if e_gpu > tol:
             bad.append('%s gpu %.3e cpu-fp32 %.3e' % (k, e_gpu, e_cpu))
