@@ -211,8 +211,80 @@ __global__ void bilstm_bwd_kernel(const float* __restrict__ dh, const float* __r
     }
 }
 
+// Register-resident form (H <= 64): thread (q, k) keeps W_hh[qH..(q+1)H-1][k] (its quarter of column k) in
+// registers, da_t is broadcast from LDS with 16-byte reads; the saved gates of step t-1 are prefetched.
+template <int H>
+__global__ __launch_bounds__(4 * H) void bilstm_bwd_reg_kernel(const float* __restrict__ dh, const float* __restrict__ save,
+                                                               const float* __restrict__ whh_f,
+                                                               const float* __restrict__ whh_r, float* __restrict__ dgx,
+                                                               int T) {
+    constexpr int G = 4 * H;
+    __shared__ __attribute__((aligned(16))) float da[G];
+    __shared__ float dhn[H];
+    __shared__ float part[4 * H];
+    const int n = blockIdx.x, dir = blockIdx.y;
+    const int j = threadIdx.x;
+    const int q = j / H, k = j % H;
+    const float* whh = dir ? whh_r : whh_f;
+    float w[H];
+#pragma unroll
+    for (int g = 0; g < H; ++g) w[g] = whh[(long long)(q * H + g) * H + k];
+    if (j < H) dhn[j] = 0.f;
+    float dc_next = 0.f;
+    const float* svb = save + ((long long)n * 2 + dir) * T * 5 * H;
+    const float* dhp = dh + ((long long)n * 2 * H + (long long)dir * H + j) * T;
+    float* dgp = dgx + ((long long)n * 2 * G + (long long)dir * G) * T;
+    __syncthreads();
+    for (int step = T - 1; step >= 0; --step) {
+        const int t = dir ? T - 1 - step : step;
+        if (j < H) {
+            const float* sv = svb + (long long)t * 5 * H + j;
+            const float ig = sv[0], fg = sv[H], gg = sv[2 * H], og = sv[3 * H], c = sv[4 * H];
+            float c_prev = 0.f;
+            if (step > 0) c_prev = svb[(long long)(dir ? t + 1 : t - 1) * 5 * H + 4 * H + j];
+            const float dht = dhp[t] + dhn[j];
+            const float tc = tanhf(c);
+            const float d_o = dht * tc;
+            const float dc = dht * og * (1.f - tc * tc) + dc_next;
+            const float d_i = dc * gg, d_g = dc * ig, d_f = dc * c_prev;
+            dc_next = dc * fg;
+            const float a_i = d_i * ig * (1.f - ig), a_f = d_f * fg * (1.f - fg);
+            const float a_g = d_g * (1.f - gg * gg), a_o = d_o * og * (1.f - og);
+            da[j] = a_i; da[H + j] = a_f; da[2 * H + j] = a_g; da[3 * H + j] = a_o;
+            dgp[(long long)j * T + t] = a_i;
+            dgp[(long long)(H + j) * T + t] = a_f;
+            dgp[(long long)(2 * H + j) * T + t] = a_g;
+            dgp[(long long)(3 * H + j) * T + t] = a_o;
+        }
+        __syncthreads();
+        {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+            for (int g = 0; g < H; g += 4) {
+                const float4 d4 = *reinterpret_cast<const float4*>(da + q * H + g);
+                s0 = fmaf(w[g], d4.x, s0);
+                s1 = fmaf(w[g + 1], d4.y, s1);
+                s2 = fmaf(w[g + 2], d4.z, s2);
+                s3 = fmaf(w[g + 3], d4.w, s3);
+            }
+            part[q * H + k] = (s0 + s1) + (s2 + s3);
+        }
+        __syncthreads();
+        if (j < H) dhn[j] = part[j] + part[H + j] + part[2 * H + j] + part[3 * H + j];
+        __syncthreads();
+    }
+}
+
 void launch_bilstm_bwd(const float* dh, const float* save, const float* whh_f, const float* whh_r, float* dgx,
                        int N, int T, int H, hipStream_t st) {
+    static const bool reg_form = !getenv("VR_LSTM_LDS");
+    if (reg_form && (H == 64 || H == 32 || H == 16)) {
+        if (H == 64) hipLaunchKernelGGL(bilstm_bwd_reg_kernel<64>, dim3(N, 2), dim3(256), 0, st, dh, save, whh_f, whh_r, dgx, T);
+        else if (H == 32) hipLaunchKernelGGL(bilstm_bwd_reg_kernel<32>, dim3(N, 2), dim3(128), 0, st, dh, save, whh_f, whh_r, dgx, T);
+        else hipLaunchKernelGGL(bilstm_bwd_reg_kernel<16>, dim3(N, 2), dim3(64), 0, st, dh, save, whh_f, whh_r, dgx, T);
+        VR_HIP(hipGetLastError());
+        return;
+    }
     const int G = 4 * H;
     const int threads = ((G + 63) / 64) * 64;
     const size_t lds = (size_t)(G * H + G + H + 4 * H) * sizeof(float);
@@ -227,20 +299,68 @@ void launch_bilstm_bwd(const float* dh, const float* save, const float* whh_f, c
     VR_HIP(hipGetLastError());
 }
 
-__global__ void lstm_whh_grad_kernel(const float* __restrict__ dgx, const float* __restrict__ hout, float* dwf, float* dwr,
-                                     int N, int T, int H, int accumulate) {
+// dW_hh[g][k] = sum_{n,t} dgx[n][g][t] * h[n][k][t -/+ 1]   (forward / reverse direction).
+// One wave per (gate row g, direction): lanes run along t (coalesced reads), the gate-gradient row stays in
+// registers across the k loop, one wave reduction per k.
+__global__ __launch_bounds__(64) void lstm_whh_grad_kernel(const float* __restrict__ dgx, const float* __restrict__ hout,
+                                                           float* dwf, float* dwr, int N, int T, int H, int accumulate) {
     const int g = blockIdx.x, dir = blockIdx.y;
     const int G = 4 * H;
+    const int lane = threadIdx.x;
     float* dw = dir ? dwr : dwf;
-    for (int k = threadIdx.x; k < H; k += blockDim.x) {
-        float s = 0.f;
-        for (int n = 0; n < N; ++n) {
-            const float* dg = dgx + ((long long)n * 2 * G + (long long)dir * G + g) * T;
-            const float* hp = hout + ((long long)n * 2 * H + (long long)dir * H + k) * T;
-            if (dir == 0) { for (int t = 1; t < T; ++t) s = fmaf(dg[t], hp[t - 1], s); }
-            else          { for (int t = 0; t < T - 1; ++t) s = fmaf(dg[t], hp[t + 1], s); }
+    const int sh = dir ? 1 : -1;                       // h index paired with dgx[t]
+    constexpr int MAXC = 64;                           // register chunks: N * ceil(T/64) <= 64
+    const int tch = (T + 63) / 64, nch = N * tch;
+    if (nch > MAXC) {                                  // long sequences / big batches: plain loop (same maths)
+        for (int k = 0; k < H; ++k) {
+            float s = 0.f;
+            for (int c = 0; c < nch; ++c) {
+                const int n = c / tch, t = (c % tch) * 64 + lane;
+                const int th = t + sh;
+                if (t < T && th >= 0 && th < T)
+                    s = fmaf(dgx[((long long)n * 2 * G + (long long)dir * G + g) * T + t],
+                             hout[((long long)n * 2 * H + (long long)dir * H + k) * T + th], s);
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+            if (lane == 0) dw[g * H + k] = accumulate ? dw[g * H + k] + s : s;
         }
-        dw[g * H + k] = accumulate ? dw[g * H + k] + s : s;
+        return;
+    }
+    // chunk c = (n, 64-frame block tc), walked with incremental counters (no divisions in the unrolled loops)
+    float dgr[MAXC];
+    {
+        int n = 0, tc = 0;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            float v = 0.f;
+            if (c < nch) {
+                const int t = tc * 64 + lane, th = t + sh;
+                if (t < T && th >= 0 && th < T) v = dgx[((long long)n * 2 * G + (long long)dir * G + g) * T + t];
+            }
+            dgr[c] = v;
+            if (++tc == tch) { tc = 0; ++n; }
+        }
+    }
+    const long long hstride = (long long)2 * H * T;                 // sample stride of hout
+    for (int k = 0; k < H; ++k) {
+        const float* hk = hout + ((long long)dir * H + k) * T;
+        float s0 = 0.f, s1 = 0.f;
+        int n = 0, tc = 0;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            if (c < nch) {
+                int th = tc * 64 + lane + sh;
+                th = th < 0 ? 0 : (th >= T ? T - 1 : th);            // (the paired dgr entry is 0 there)
+                const float hv = hk[(long long)n * hstride + th];
+                if (c & 1) s1 = fmaf(dgr[c], hv, s1); else s0 = fmaf(dgr[c], hv, s0);
+            }
+            if (++tc == tch) { tc = 0; ++n; }
+        }
+        float s = s0 + s1;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) dw[g * H + k] = accumulate ? dw[g * H + k] + s : s;
     }
 }
 
