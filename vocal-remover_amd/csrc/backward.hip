@@ -298,19 +298,28 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(Tensor x, const float* 
     }
 }
 
-__global__ void reduce_rows_kernel(const float* __restrict__ part, long long stride, int P, float* __restrict__ out,
-                                   long long n, int accumulate, float scale) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// out[i] (+)= scale * sum_p part[p*stride + i]   (double accumulation, fixed order: deterministic).
+// One workgroup per output element: 256 threads stride over the P partials, tree-reduce in LDS.
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, long long stride, int P,
+                                                          float* __restrict__ out, long long n, int accumulate, float scale) {
+    __shared__ double red[256];
+    const long long i = blockIdx.x;
     double s = 0.0;
-    for (int p = 0; p < P; ++p) s += (double)part[p * stride + i];
-    const float v = (float)s * scale;
-    out[i] = accumulate ? out[i] + v : v;
+    for (int p = threadIdx.x; p < P; p += 256) s += (double)part[(long long)p * stride + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float v = (float)red[0] * scale;
+        out[i] = accumulate ? out[i] + v : v;
+    }
 }
 void launch_reduce_rows(const float* part, long long stride, int P, float* out, long long n, int accumulate, float scale,
                         hipStream_t st) {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, stride, P, out, n,
-                       accumulate, scale);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)n), dim3(256), 0, st, part, stride, P, out, n, accumulate, scale);
     VR_HIP(hipGetLastError());
 }
 
