@@ -299,74 +299,53 @@ void launch_bilstm_bwd(const float* dh, const float* save, const float* whh_f, c
     VR_HIP(hipGetLastError());
 }
 
-// dW_hh[g][k] = sum_{n,t} dgx[n][g][t] * h[n][k][t -/+ 1]   (forward / reverse direction).
-// One wave per (gate row g, direction): lanes run along t (coalesced reads), the gate-gradient row stays in
-// registers across the k loop, one wave reduction per k.
-__global__ __launch_bounds__(64) void lstm_whh_grad_kernel(const float* __restrict__ dgx, const float* __restrict__ hout,
-                                                           float* dwf, float* dwr, int N, int T, int H, int accumulate) {
-    const int g = blockIdx.x, dir = blockIdx.y;
+// dW_hh[g][k] = sum_{n,t} dgx[n][g][t] * h[n][k][t -/+ 1]   (forward / reverse direction): a small GEMM over (n,t).
+// Workgroup = 16 gate rows x 64 hidden columns; per (sample, 64-frame block) the dgx rows and the shifted h rows
+// are staged in LDS with coalesced reads, thread (k, 4 gate rows) accumulates 64 frames from LDS.
+__global__ __launch_bounds__(256) void lstm_whh_grad_kernel(const float* __restrict__ dgx, const float* __restrict__ hout,
+                                                            float* dwf, float* dwr, int N, int T, int H, int accumulate) {
+    __shared__ float hs[64][65];
+    __shared__ float dgs[16][64];
+    const int g0 = blockIdx.x * 16, dir = blockIdx.y, k0 = blockIdx.z * 64;
     const int G = 4 * H;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;      // wq: which 4 of the 16 gate rows / staging row phase
     float* dw = dir ? dwr : dwf;
-    const int sh = dir ? 1 : -1;                       // h index paired with dgx[t]
-    constexpr int MAXC = 64;                           // register chunks: N * ceil(T/64) <= 64
-    const int tch = (T + 63) / 64, nch = N * tch;
-    if (nch > MAXC) {                                  // long sequences / big batches: plain loop (same maths)
-        for (int k = 0; k < H; ++k) {
-            float s = 0.f;
-            for (int c = 0; c < nch; ++c) {
-                const int n = c / tch, t = (c % tch) * 64 + lane;
-                const int th = t + sh;
-                if (t < T && th >= 0 && th < T)
-                    s = fmaf(dgx[((long long)n * 2 * G + (long long)dir * G + g) * T + t],
-                             hout[((long long)n * 2 * H + (long long)dir * H + k) * T + th], s);
+    const int sh = dir ? 1 : -1;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < N; ++n) {
+        for (int t0 = 0; t0 < T; t0 += 64) {
+            const int t = t0 + lane, th = t + sh;
+            const bool ok = t < T && th >= 0 && th < T;
+            for (int r = wq; r < 64; r += 4) {
+                const int k = k0 + r;
+                hs[r][lane] = (ok && k < H) ? hout[((long long)n * 2 * H + (long long)dir * H + k) * T + th] : 0.f;
             }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-            if (lane == 0) dw[g * H + k] = accumulate ? dw[g * H + k] + s : s;
-        }
-        return;
-    }
-    // chunk c = (n, 64-frame block tc), walked with incremental counters (no divisions in the unrolled loops)
-    float dgr[MAXC];
-    {
-        int n = 0, tc = 0;
-#pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            float v = 0.f;
-            if (c < nch) {
-                const int t = tc * 64 + lane, th = t + sh;
-                if (t < T && th >= 0 && th < T) v = dgx[((long long)n * 2 * G + (long long)dir * G + g) * T + t];
+            for (int r = wq; r < 16; r += 4) {
+                const int g = g0 + r;
+                dgs[r][lane] = (ok && g < G) ? dgx[((long long)n * 2 * G + (long long)dir * G + g) * T + t] : 0.f;
             }
-            dgr[c] = v;
-            if (++tc == tch) { tc = 0; ++n; }
+            __syncthreads();
+#pragma unroll 8
+            for (int tt = 0; tt < 64; ++tt) {
+                const float hv = hs[lane][tt];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = fmaf(dgs[wq * 4 + q][tt], hv, acc[q]);
+            }
+            __syncthreads();
         }
     }
-    const long long hstride = (long long)2 * H * T;                 // sample stride of hout
-    for (int k = 0; k < H; ++k) {
-        const float* hk = hout + ((long long)dir * H + k) * T;
-        float s0 = 0.f, s1 = 0.f;
-        int n = 0, tc = 0;
+    const int k = k0 + lane;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            if (c < nch) {
-                int th = tc * 64 + lane + sh;
-                th = th < 0 ? 0 : (th >= T ? T - 1 : th);            // (the paired dgr entry is 0 there)
-                const float hv = hk[(long long)n * hstride + th];
-                if (c & 1) s1 = fmaf(dgr[c], hv, s1); else s0 = fmaf(dgr[c], hv, s0);
-            }
-            if (++tc == tch) { tc = 0; ++n; }
-        }
-        float s = s0 + s1;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-        if (lane == 0) dw[g * H + k] = accumulate ? dw[g * H + k] + s : s;
+    for (int q = 0; q < 4; ++q) {
+        const int g = g0 + wq * 4 + q;
+        if (g < G && k < H) dw[g * H + k] = accumulate ? dw[g * H + k] + acc[q] : acc[q];
     }
 }
 
 void launch_lstm_whh_grad(const float* dgx, const float* hout, float* dwhh_f, float* dwhh_r, int N, int T, int H,
                           int accumulate, hipStream_t st) {
-    hipLaunchKernelGGL(lstm_whh_grad_kernel, dim3(4 * H, 2), dim3(64), 0, st, dgx, hout, dwhh_f, dwhh_r, N, T, H, accumulate);
+    hipLaunchKernelGGL(lstm_whh_grad_kernel, dim3((4 * H + 15) / 16, 2, (H + 63) / 64), dim3(256), 0, st, dgx, hout, dwhh_f,
+                       dwhh_r, N, T, H, accumulate);
     VR_HIP(hipGetLastError());
 }
 
