@@ -22,7 +22,27 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
     const int r0 = (int)((long long)blockIdx.x * rows / gridDim.x), r1 = (int)((long long)(blockIdx.x + 1) * rows / gridDim.x);
     const float sc = a.aff ? a.aff[2 * (a.aff_bcast ? 0 : c)] : 1.f, sh = a.aff ? a.aff[2 * (a.aff_bcast ? 0 : c) + 1] : 0.f;
     float s1 = 0.f, s2 = 0.f;
-    const int total = (r1 - r0) * a.W;
+    const bool vec = (a.W & 3) == 0 && (a.sH & 3) == 0 && (a.sC & 3) == 0 && (a.sN & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(a.z) | reinterpret_cast<uintptr_t>(a.g)) & 15) == 0;
+    if (vec) {                                   // four frames per thread, 16-byte loads
+        const int Q = a.W >> 2, total4 = (r1 - r0) * Q;
+        for (int e = threadIdx.x; e < total4; e += 256) {
+            const int r = r0 + e / Q, w = (e % Q) * 4;
+            const int n = r / a.H, h = r % a.H;
+            const long long off = (long long)n * a.sN + (long long)c * a.sC + (long long)h * a.sH + w;
+            const float4 z4 = *reinterpret_cast<const float4*>(a.z + off);
+            const float4 g4 = *reinterpret_cast<const float4*>(a.g + off);
+            const float pm = a.post ? a.post[n * a.C + c] : 1.f;
+            const float zz[4] = {z4.x, z4.y, z4.z, z4.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dy = gg[j] * pm * dact(fmaf(zz[j], sc, sh), a.slope);
+                s1 += dy;
+                s2 = fmaf(dy, zz[j], s2);
+            }
+        }
+    }
+    const int total = vec ? 0 : (r1 - r0) * a.W;
     for (int e = threadIdx.x; e < total; e += 256) {
         const int r = r0 + e / a.W, w = e % a.W;
         const int n = r / a.H, h = r % a.H;
@@ -76,6 +96,35 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdArgs a, int n
 }
 
 // pass 2: G <- dz in place.  coef == null: no BatchNorm (dz = dy).
+// four frames per thread (16-byte loads / store); chosen by launch_bn_bwd when the rows allow it
+__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(BnBwdArgs a) {
+    const long long total4 = (long long)a.N * a.C * a.H * (a.W >> 2);
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total4) return;
+    const int Q = a.W >> 2;
+    const int w = (int)(gid % Q) * 4;
+    long long t = gid / Q;
+    const int h = (int)(t % a.H); t /= a.H;
+    const int c = (int)(t % a.C);
+    const int n = (int)(t / a.C);
+    const long long off = (long long)n * a.sN + (long long)c * a.sC + (long long)h * a.sH + w;
+    const int ca = a.aff_bcast ? 0 : c;
+    const float sc = a.aff ? a.aff[2 * ca] : 1.f, sh = a.aff ? a.aff[2 * ca + 1] : 0.f;
+    const float pm = a.post ? a.post[n * a.C + c] : 1.f;
+    float kA = 1.f, kB = 0.f, kC = 0.f;
+    if (a.coef) { kA = a.coef[3 * c]; kB = a.coef[3 * c + 1]; kC = a.coef[3 * c + 2]; }
+    const float4 z4 = *reinterpret_cast<const float4*>(a.z + off);
+    const float4 g4 = *reinterpret_cast<const float4*>(a.g + off);
+    const float zz[4] = {z4.x, z4.y, z4.z, z4.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float dy = gg[j] * pm * dact(fmaf(zz[j], sc, sh), a.slope);
+        o[j] = a.coef ? fmaf(kA, dy, fmaf(kB, zz[j], kC)) : dy;
+    }
+    *reinterpret_cast<float4*>(a.g + off) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
     const long long total = (long long)a.N * a.C * a.H * a.W;
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -113,7 +162,10 @@ void launch_bn_bwd(const BnBwdArgs& a, hipStream_t st) {
         VR_HIP(hipGetLastError());
     }
     const long long total = (long long)a.N * a.C * a.H * a.W;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+    const bool vec = (a.W & 3) == 0 && (a.sH & 3) == 0 && (a.sC & 3) == 0 && (a.sN & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(a.z) | reinterpret_cast<uintptr_t>(a.g)) & 15) == 0;
+    if (vec) hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
     VR_HIP(hipGetLastError());
 }
 
