@@ -130,8 +130,19 @@ void Model::bwd_conv(TapeRec& r) {
         w.Cout = L.Cout; w.CoutPad = L.CoutPad;
         w.part = ws.allocf(wgrad_scratch_floats(w, shp));
         if (!dry) {
+            // The weight gradient is off the critical path (dz -> data gradient -> previous layer): it runs on the
+            // side stream beside the data-gradient / BatchNorm-backward chain, so the element-wise passes and the
+            // tails of one stream's kernels fill the other's bubbles.  backward() joins before returning.
+            static const bool overlap = !getenv("VR_NO_WGRAD_OVERLAP");
+            hipStream_t wst = stream;
+            if (overlap && !profiling && side_stream) {
+                VR_HIP(hipEventRecord(ev_fork, stream));          // dz (and every forward tensor) is ready here
+                VR_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
+                wst = side_stream;
+                wgrad_on_side = true;
+            }
             record_begin(0, 2.0 * N * (double)(r.batch_as_h ? 1 : f.Hout) * f.Wout * (double)L.Cout * L.Cin * L.KS * L.KS);
-            launch_wgrad(w, shp, grad_of(L.w), 1, stream);
+            launch_wgrad(w, shp, grad_of(L.w), 1, wst);
             record_end();
         }
     }
@@ -232,6 +243,15 @@ void Model::bwd_conv(TapeRec& r) {
 }
 
 void Model::backward() {
+    struct Join {                                      // the side stream's weight gradients must land before Adam
+        Model* m;
+        ~Join() {
+            if (!m->wgrad_on_side) return;
+            m->wgrad_on_side = false;
+            hipEventRecord(m->ev_join, m->side_stream);
+            hipStreamWaitEvent(m->stream, m->ev_join, 0);
+        }
+    } join{this};
     for (size_t k = tape.size(); k-- > 0;) {
         TapeRec& r = tape[k];
         switch (r.kind) {
@@ -538,6 +558,7 @@ void Model::debug_conv_bwd(const float* x, int N, int Cin, int H, int W, const f
     }
     bwd_conv(r);
     VR_HIP(hipStreamSynchronize(stream));
+    if (wgrad_on_side) { VR_HIP(hipStreamSynchronize(side_stream)); wgrad_on_side = false; }   // the weight gradient ran there
     VR_HIP(hipMemcpy(dx_out, dgx, xin * 4, hipMemcpyDeviceToHost));
     std::vector<float> gk(wk.size());
     VR_HIP(hipMemcpy(gk.data(), dgw, gk.size() * 4, hipMemcpyDeviceToHost));
