@@ -788,10 +788,11 @@ Tensor Model::run_net(const Tensor& x) {
     };
     Tensor v;
     // The low-band chain (stg1_low -> stg2_low) and the high-band chain (stg1_high -> stg2_high) are
-    // independent until stage 3 (lib/nets.py:91-98).  In eval mode they run on two HIP streams so the
+    // independent until stage 3 (lib/nets.py:91-98).  They run on two HIP streams (forward of both modes) so the
     // small 1/16-resolution layers of one chain fill the CUs the other leaves idle.
     // (not while per-kernel HIP-event timing is on: overlapping kernels would inflate each other's time)
-    const bool fork = !dry && !training && !profiling && side_stream != nullptr;
+    static const bool train_fork = !getenv("VR_NO_TRAIN_FORK");
+    const bool fork = !dry && (!training || train_fork) && !profiling && side_stream != nullptr;
     hipStream_t main_stream = stream;
     if (fork) {
         VR_HIP(hipEventRecord(ev_fork, main_stream));
