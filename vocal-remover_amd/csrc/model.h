@@ -207,6 +207,7 @@ private:
         float* save = nullptr;                 // LSTM gate/cell record
         float* buf0 = nullptr;                 // kind-specific buffers
         float* buf1 = nullptr;
+        int chain = 0;                         // 1: high-band chain of stages 1-2 (independent of the low-band chain)
     };
     std::vector<TapeRec> tape;
     Arena gs;                                            // gradients of activations (zeroed per step)

@@ -805,10 +805,12 @@ Tensor Model::run_net(const Tensor& x) {
     v = half(aux2, 0);
     Tensor l2 = run_conv(tail2, {SrcSpec{l2r}}, B, &v, nullptr, false);
     if (fork) stream = side_stream;
+    const size_t tape_hi0 = tape.size();
     v = half(aux1, 1);
     Tensor h1 = run_basenet(nets_[1], {SrcSpec{xh}}, B, &v);
     v = half(aux2, 1);
     Tensor h2 = run_basenet(nets_[3], {SrcSpec{xh}, SrcSpec{h1}}, B, &v);
+    for (size_t i = tape_hi0; i < tape.size(); ++i) tape[i].chain = 1;    // backward may run these beside the low chain
     if (fork) {
         VR_HIP(hipEventRecord(ev_join, side_stream));
         stream = main_stream;

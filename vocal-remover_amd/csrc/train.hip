@@ -252,8 +252,33 @@ void Model::backward() {
             hipStreamWaitEvent(m->stream, m->ev_join, 0);
         }
     } join{this};
+    // Stages 1-2: the high-band records (chain 1) are independent of the low-band ones; in the reversed tape
+    // they come first after stage 3, so they are enqueued on a second stream and the low chain follows on the main one.
+    static const bool bwd_fork = !getenv("VR_NO_BWD_FORK");
+    hipStream_t main_stream = stream;
+    hipStream_t hi_stream = (bwd_fork && !dry && !profiling && !lanes.empty()) ? lanes[0].main : nullptr;
+    int cur_chain = 0;
+    bool hi_used = false;
+    struct Restore {
+        Model* m; hipStream_t s; hipStream_t hi; hipEvent_t ev; bool* used;
+        ~Restore() {
+            m->stream = s;
+            if (*used) { hipEventRecord(ev, hi); hipStreamWaitEvent(s, ev, 0); }
+        }
+    } restore{this, main_stream, hi_stream, hi_stream ? lanes[0].done : nullptr, &hi_used};
     for (size_t k = tape.size(); k-- > 0;) {
         TapeRec& r = tape[k];
+        if (hi_stream && r.chain != cur_chain) {
+            if (r.chain == 1) {                    // entering the high chain: everything so far (stage 3) must be done
+                VR_HIP(hipEventRecord(lanes[0].start, main_stream));
+                VR_HIP(hipStreamWaitEvent(hi_stream, lanes[0].start, 0));
+                stream = hi_stream;
+                hi_used = true;
+            } else {
+                stream = main_stream;
+            }
+            cur_chain = r.chain;
+        }
         switch (r.kind) {
         case TK_CONV:
             bwd_conv(r);
