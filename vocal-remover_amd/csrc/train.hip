@@ -350,6 +350,7 @@ void Model::train_fwd_bwd_api(const float* X, const float* Y, bool on_dev, int B
         float* lpart = ws.allocf((size_t)head_loss_blocks(f3));
         float* wpart = ws.allocf((size_t)thin_wgrad_blocks(f3) * 2 * f3.C);
         if (!dry) {
+            if (gs_clear_pending) { VR_HIP(hipStreamWaitEvent(stream, lanes[0].join, 0)); gs_clear_pending = false; }
             const double ntot = (double)B * 2 * output_bin * T;
             launch_head_loss(f3, out_w->dev, xd, yd, output_bin, (float)(1.0 / (ntot * accumulation_steps)), dlogit, maskd,
                              lpart, lossd, (float)(1.0 / ntot), stream);
@@ -376,7 +377,16 @@ void Model::train_fwd_bwd_api(const float* X, const float* Y, bool on_dev, int B
             gs.cap = need_gs + (need_gs >> 4);
         }
         ws.reset(); gs.reset();
-        VR_HIP(hipMemsetAsync(gs.base, 0, need_gs, stream));
+        // the activation-gradient arena is only touched from the loss kernels on: clear it beside the forward pass
+        if (!lanes.empty()) {
+            VR_HIP(hipEventRecord(lanes[0].fork, stream));            // (previous step's consumers of gs are done)
+            VR_HIP(hipStreamWaitEvent(lanes[0].main, lanes[0].fork, 0));
+            VR_HIP(hipMemsetAsync(gs.base, 0, need_gs, lanes[0].main));
+            VR_HIP(hipEventRecord(lanes[0].join, lanes[0].main));
+            gs_clear_pending = true;
+        } else {
+            VR_HIP(hipMemsetAsync(gs.base, 0, need_gs, stream));
+        }
     }
     // ---- dropout keep-masks (lib/layers.py:90: Dropout2d(0.1) on the five ASPP outputs) ----------------------
     dropout_dev = nullptr;
