@@ -130,6 +130,23 @@ def test_stft_restatement_vs_torch():
     assert np.abs(back - wave[:, :back.shape[1]]).max() < 1e-5
 
 
+def test_stft_restatement_vs_scipy():
+    """A second, independent implementation (scipy.signal) of the same transform: periodic Hann, centred frames
+    with zero padding of n_fft/2 -- librosa 0.10's defaults, which the reference relies on (lib/spec_utils.py:26-31).
+    scipy scales by 1/sum(window); librosa does not."""
+    import scipy.signal as sig
+    wave = separator.synth_wave(1.5, seed=4)
+    n_fft, hop = 2048, 1024
+    spec = stft_np.wave_to_spectrogram(wave, hop, n_fft)
+    win = sig.get_window('hann', n_fft, fftbins=True)
+    _, _, Z = sig.stft(wave.astype(np.float64), window=win, nperseg=n_fft, noverlap=n_fft - hop, nfft=n_fft,
+                       boundary='zeros', padded=False, return_onesided=True)
+    Z = Z * win.sum()
+    T = spec.shape[2]
+    assert Z.shape[1] == 1025 and Z.shape[2] >= T
+    assert np.abs(spec - Z[:, :, :T]).max() < 2e-5 * np.abs(Z).max()
+
+
 # ---- training sample pipeline (SURVEY §8f rank 2): lib/dataset.py VocalRemoverTrainingSet ---------------------
 def _synthetic_training_set(tmp_path, bins=33, lengths=(90, 140, 75), seed=0):
     """Cached spectrograms in the reference's on-disk format: [T, 2, bins] complex64 .npy + coef."""
