@@ -99,3 +99,46 @@ def test_hip_full_net_fixture(vr):
     got = model.predict_mask(xf.to('cuda:0')).cpu().numpy()
     diff = np.abs(got - G['full_mask'])
     assert diff.max() < 1e-4 and diff.mean() < 1e-5
+
+
+# ---- training input pipeline fixtures (tests/golden/make_golden_dataset.py, the reference's lib/dataset.py) ------
+GD = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'dataset_pipeline.npz'))
+_DS_CROP, _DS_PARAMS, _DS_SEEDS = 32, dict(reduction_rate=0.5, mixup_rate=0.5, mixup_alpha=0.4), 12
+
+
+def _golden_training_set(tmp_path):
+    ts = []
+    for i in range(3):
+        paths = []
+        for tag in ('X', 'y'):
+            p = str(tmp_path / ('song%d_%s.npy' % (i, tag)))
+            np.save(p, GD['song%d_%s' % (i, tag)])
+            paths.append(p)
+        ts.append([paths[0], paths[1], GD['coef%d' % i][()]])
+    return ts * 2
+
+
+def test_oracle_training_pipeline_reproduces_reference_fixture(tmp_path):
+    from oracle import dataset_np
+    ts = _golden_training_set(tmp_path)
+    for seed in range(_DS_SEEDS):
+        np.random.seed(seed)
+        X, y = dataset_np.training_sample(ts, seed % len(ts), _DS_CROP, _DS_PARAMS['reduction_rate'], GD['reduction_weight'],
+                                          _DS_PARAMS['mixup_rate'], _DS_PARAMS['mixup_alpha'])
+        assert np.abs(X - GD['seed%d_X' % seed]).max() < 1e-6 and np.abs(y - GD['seed%d_y' % seed]).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_hip_training_pipeline_reproduces_reference_fixture(vr, tmp_path):
+    """Device pipeline (host draws + vr_augment_batch) against the reference's own outputs, no oracle in the loop."""
+    model = vr.nets.CascadedNet(512, 256, 8, 32)
+    model.to(torch.device('cuda:0'))
+    ts = _golden_training_set(tmp_path)
+    ds = vr.dataset.VocalRemoverTrainingSet(ts, cropsize=_DS_CROP, reduction_weight=GD['reduction_weight'], model=model,
+                                            **_DS_PARAMS)
+    for seed in range(_DS_SEEDS):
+        np.random.seed(seed)
+        X, y = ds[seed % len(ds)]
+        scale = float(np.abs(GD['seed%d_X' % seed]).max()) + 1e-6
+        assert float(np.abs(X.cpu().numpy() - GD['seed%d_X' % seed]).max()) < 3e-6 * scale, seed
+        assert float(np.abs(y.cpu().numpy() - GD['seed%d_y' % seed]).max()) < 3e-6 * scale, seed
