@@ -792,7 +792,8 @@ Tensor Model::run_net(const Tensor& x) {
     // small 1/16-resolution layers of one chain fill the CUs the other leaves idle.
     // (not while per-kernel HIP-event timing is on: overlapping kernels would inflate each other's time)
     static const bool train_fork = !getenv("VR_NO_TRAIN_FORK");
-    const bool fork = !dry && (!training || train_fork) && !profiling && side_stream != nullptr;
+    static const bool band_fork = !getenv("VR_NO_BAND_FORK");
+    const bool fork = band_fork && !dry && (!training || train_fork) && !profiling && side_stream != nullptr;
     hipStream_t main_stream = stream;
     if (fork) {
         VR_HIP(hipEventRecord(ev_fork, main_stream));
