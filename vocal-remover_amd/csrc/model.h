@@ -144,6 +144,7 @@ public:
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;          // eval mode: the high-band chain runs here
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool band_fork_active = false;                       // run_net: the side stream currently carries the high-band chain
     bool gs_clear_pending = false;                       // training: the gs memset runs on lanes[0].main beside the forward
     bool wgrad_on_side = false;                          // training: weight gradients in flight on side_stream
     // eval mode, second lane: the crops of a batch are independent, so separate() runs the two halves

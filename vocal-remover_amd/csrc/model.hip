@@ -756,9 +756,24 @@ Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, co
         h = run_conv(B.dec[i], {up, SrcSpec{e[3 - i]}}, N, nullptr, nullptr, false);
         tap(p + ".dec" + std::to_string(4 - i), h);
     }
+    // Eval, stage 3 (the side stream is idle there): the x2 upsample of h (HBM-bound) runs beside the LSTM branch
+    // (latency-bound); both only need h, and dec1 needs both.
+    static const bool lstm_fork = !getenv("VR_NO_LSTM_FORK");
+    const bool fk = lstm_fork && !training && !dry && !profiling && side_stream != nullptr && !band_fork_active;
+    SrcSpec uh;
+    if (fk) {
+        hipStream_t ms = stream;
+        VR_HIP(hipEventRecord(ev_fork, ms));
+        VR_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
+        stream = side_stream;
+        try { uh = upsampled(h); } catch (...) { stream = ms; throw; }
+        VR_HIP(hipEventRecord(ev_join, side_stream));
+        stream = ms;
+    }
     Tensor l = run_lstm(B.lstm, h);
     tap(p + ".lstm", l);
-    SrcSpec uh = upsampled(h);
+    if (fk) VR_HIP(hipStreamWaitEvent(stream, ev_join, 0));
+    else uh = upsampled(h);
     SrcSpec ul = upsampled(l);
     Tensor o = run_conv(B.dec[3], {uh, ul, SrcSpec{e[0]}}, N, out_view, nullptr, false);
     tap(p + ".dec1", o);
@@ -798,6 +813,7 @@ Tensor Model::run_net(const Tensor& x) {
     if (fork) {
         VR_HIP(hipEventRecord(ev_fork, main_stream));
         VR_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
+        band_fork_active = true;                 // until the join: the side stream belongs to the high-band chain
     }
     Tensor l1r = run_basenet(nets_[0], {SrcSpec{xl}}, B, nullptr);
     v = half(aux1, 0);
@@ -816,6 +832,7 @@ Tensor Model::run_net(const Tensor& x) {
         VR_HIP(hipEventRecord(ev_join, side_stream));
         stream = main_stream;
         VR_HIP(hipStreamWaitEvent(main_stream, ev_join, 0));
+        band_fork_active = false;
     }
     tap("l1", l1); tap("h1", h1);
     tap("l2", l2); tap("h2", h2);
