@@ -734,12 +734,27 @@ Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, co
     if (training) cat4.g = gs.allocf((size_t)N * cat4.C * x5.H * x5.W);
     if (training) { cat4.aff0 = B.aspp_aff; cat4.slope = 0.f; }      // eval: the branch convs store final activations
     Conv* branch[4] = {&B.aspp_c2, &B.aspp_d[0], &B.aspp_d[1], &B.aspp_d[2]};
+    // Eval, stage 3: the four branch convs are independent and each fills < 256 CUs at 1/16 resolution --
+    // two of them go to the idle side stream.
+    static const bool aspp_fork = !getenv("VR_NO_ASPP_FORK");
+    const bool afk = aspp_fork && !training && !dry && !profiling && side_stream != nullptr && !band_fork_active;
+    hipStream_t aspp_main = stream;
+    if (afk) {
+        VR_HIP(hipEventRecord(ev_fork, aspp_main));
+        VR_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
+    }
     for (int j = 0; j < 4; ++j) {
         Tensor v = cat4;
         v.C = C8;
         v.p = dry ? cat4.p : cat4.p + (long long)j * C8 * cat4.sC;
         if (training && !dry) v.g = cat4.g + (long long)j * C8 * cat4.sC;
-        run_conv(*branch[j], {SrcSpec{x5}}, N, &v, nullptr, false);
+        if (afk) stream = (j & 1) ? side_stream : aspp_main;
+        try { run_conv(*branch[j], {SrcSpec{x5}}, N, &v, nullptr, false); } catch (...) { stream = aspp_main; throw; }
+    }
+    if (afk) {
+        stream = aspp_main;
+        VR_HIP(hipEventRecord(ev_join, side_stream));
+        VR_HIP(hipStreamWaitEvent(aspp_main, ev_join, 0));
     }
     SrcSpec s1{f1};
     s1.bcastH = x5.H;          // bilinear from H=1 with align_corners=True is a broadcast along H
