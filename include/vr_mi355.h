@@ -35,7 +35,8 @@ enum vr_status {
     VR_ERR_OOM = -4,            /* workspace planning / allocation failure                         */
     VR_ERR_CROP_CENTER = -5,    /* reference ValueError of spec_utils.crop_center (spec_utils.py:15) */
     VR_ERR_EMPTY_MASK = -6,     /* reference `assert mask.size()[3] > 0` (nets.py:129,139)         */
-    VR_ERR_INDEX = -7           /* reference IndexError in merge_artifacts (spec_utils.py:65, empty idx) */
+    VR_ERR_INDEX = -7,          /* reference IndexError in merge_artifacts (spec_utils.py:65, empty idx) */
+    VR_ERR_COMM = -8            /* RCCL could not be loaded, or a collective failed                        */
 };
 
 const char* vr_last_error(void);
@@ -61,7 +62,8 @@ int vr_set_mode(vr_handle h, int training);
  * ~1e-6 relative per conv -- the same class of difference as cuDNN's algorithm choice in the
  * reference); 0 = direct kernels only.  Inference always uses Winograd where applicable.
  * "adam_reset": zero the Adam moments and the step counter (what constructing a new
- * torch.optim.Adam does; train.py:215-218).                                                          */
+ * torch.optim.Adam does; train.py:215-218).  "serial_exec" (default 0): 1 = every kernel on the handle's one
+ * stream, no lanes / side streams (tests: results must not depend on the concurrent executor).            */
 int vr_set_option(vr_handle h, const char* name, int value);
 
 /* CascadedNet.forward (mode 0) / predict_mask (mode 1) / predict (mode 2)   lib/nets.py:82-141
@@ -118,13 +120,38 @@ int vr_augment_batch(vr_handle h, const float* X, const float* y, const float* X
 int vr_adam_step(vr_handle h, float lr, float b1, float b2, float eps, float grad_scale);
 int vr_zero_grad(vr_handle h);                                          /* model.zero_grad(), train.py:96 */
 int vr_get_grad(vr_handle h, const char* key, float* host, int64_t capacity_bytes);   /* param.grad, torch layout */
-/* nn.Dropout2d(0.1) on the five ASPP outputs (lib/layers.py:90).  mode 0: off; 1: library RNG (seed);
+/* nn.Dropout2d(0.1) on the five ASPP outputs (lib/layers.py:90), live in train mode.  mode 1 (the DEFAULT, as in
+ * the reference): device-side counter-based generator keyed on (seed, number of train-mode forwards so far), a
+ * fresh draw per forward; 0: off (explicit opt-out, parity tests);
  * 2: injected keep-masks [5][B][8*nout] holding 0 or 1/0.9 (parity tests), nets in the order
  * stg1_low, stg1_high, stg2_low, stg2_high, stg3_full, row pitch 8*c of each net.                   */
 int vr_set_dropout(vr_handle h, int mode, uint64_t seed, const float* masks, int B);
 /* The single flat fp32 gradient bucket (device pointer + element count) for the data-parallel
  * all-reduce (RCCL through torch.distributed): all-reduce it in place, then vr_adam_step.           */
 int vr_grad_arena(vr_handle h, float** device_ptr, int64_t* numel);
+
+/* One batch of train.validate_epoch (train.py:117-127), eval mode:
+ *   y_pred = model.predict(X); y = spec_utils.crop_center(y, y_pred); loss = nn.L1Loss()(y_pred, y)
+ * X, y: [B, 2, bins, T] fp32.  *loss_out = loss.item().  Forward, crop and the L1 reduction run on the device. */
+int vr_validate_step(vr_handle h, const float* X, const float* y, int on_device, int B, int T, float* loss_out);
+
+/* ---- data-parallel exchange.  The reference has none: train.py:211-213 takes one --gpu. ----
+ * One process per GPU, one handle per process.  Rank 0 draws an id (vr_comm_unique_id, 128 bytes = ncclUniqueId),
+ * hands it to the other ranks by any host channel (INTEGRATION.md uses torch.distributed's store), every rank calls
+ * vr_comm_init.  Per optimizer step: vr_train_step -> vr_allreduce_grads -> vr_adam_step(grad_scale = 1/world).
+ * Parity definition: N ranks == the reference's gradient accumulation with accumulation_steps = N (train.py:91-96).
+ * RCCL is dlopen()ed on first use (the copy already mapped in the process, e.g. torch's, else the system's).      */
+#define VR_COMM_ID_BYTES 128
+int vr_comm_unique_id(void* id_out);
+int vr_comm_init(vr_handle h, int rank, int world_size, const void* id);
+int vr_comm_destroy(vr_handle h);
+/* In-place SUM all-reduce of the flat gradient arena (vr_grad_arena) over RCCL/xGMI, enqueued on the handle's stream
+ * (no host synchronisation; vr_adam_step follows on the same stream).  wire_dtype 0: fp32 bucket; 1: bf16 bucket
+ * (rounded to bf16, summed in bf16 on the wire, widened back to the fp32 arena: half the bytes per link).         */
+int vr_allreduce_grads(vr_handle h, int wire_dtype);
+/* Rank `root`'s parameters, BatchNorm buffers and num_batches_tracked (and, with_optimizer != 0, the Adam moments and
+ * step count) replace every rank's: replicas start identical (what DistributedDataParallel does at construction). */
+int vr_broadcast_params(vr_handle h, int root, int with_optimizer);
 
 /* ---- measurement hooks (bench.py) ----------------------------------------------------------- */
 /* Bracket subsequent calls: every MFMA-conv launch is timed with HIP events on the handle's stream.
@@ -153,6 +180,10 @@ int vr_debug_conv2d_backward(vr_handle h, const float* x, int N, int Cin, int H,
  * weight [T] (lib/spec_utils.py:64-87), incl. the reference's IndexError / ValueError cases.        */
 int vr_debug_merge_artifacts_weight(const float* frame_min, int T, float thres, int min_range, int fade_size,
                                     float* weight_out);
+/* One kernel of the training path in isolation, host pointers in and out (csrc/debug.hip lists the names, their
+ * dims / float parameters / inputs / outputs): bn_backward, lstm, upsample, pool, thin, head_loss, rows, adam.      */
+int vr_debug_kernel(vr_handle h, const char* name, const int64_t* dims, int ndims, const float* fparams, int nfparams,
+                    const float* const* inputs, int ninputs, float* const* outputs, int noutputs);
 /* Record intermediate activations of the next vr_forward and read them back (post-activation). */
 int vr_debug_record_taps(vr_handle h, int enable);
 int64_t vr_debug_get_tap(vr_handle h, const char* name, float* host, int64_t capacity_floats, int64_t* shape4);

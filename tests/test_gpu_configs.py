@@ -1,0 +1,275 @@
+"""GPU parity on the configurations BASELINE.json itself names (VERDICT r1 "what's weak" 1-2), through the C ABI:
+
+  configs[1]  S30 song (30 s stereo 44.1 kHz -> 1292 frames -> 11 crops), full CascadedNet(2048,1024,32,128),
+              Separator.separate_wave with batchsize=0 = the benchmarked executor (2 lanes x 2 band streams + side-stream
+              ASPP / upsample), vs the CPU oracle chain stft_np -> separator -> istft (inference.py:147-176);
+  configs[2]  the same with --tta (23 crops, complex lexicographic-max normaliser, inference.py:83-102);
+  race check  the concurrent executor vs vr_set_option("serial_exec", 1) (every kernel on one stream) and vs itself;
+  configs[3]  the full-net train step (train.py:77-96) at [2,2,1025,256] (batch 2 so the fp64 CPU oracle fits in RAM);
+  train-mode forward (`model(X)` under model.train()) and validate_epoch values against fixtures generated
+  from the REFERENCE itself (tests/golden/make_golden_validate.py).
+
+Tolerances (fp32): waves and spectrogram stems 1e-4 of max|X|; mask max-abs 1e-4 and mean-abs 1e-5; loss 2e-6;
+BatchNorm running statistics 1e-4 of their scale; gradients: see test_full_net_train_step.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cascaded_net, separator, stft_np, train_step, weights
+
+pytestmark = pytest.mark.gpu
+
+HOP, N_FFT, CROP = 1024, 2048, 256
+GV = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'validate_epoch.npz'))
+
+
+@pytest.fixture(scope='module')
+def full(vr):
+    sd = weights.make_state_dict(1234)
+    model = vr.nets.CascadedNet(N_FFT, HOP, 32, 128)
+    model.load_state_dict(sd)
+    model.to(torch.device('cuda:0'))
+    model.eval()
+    return model, sd
+
+
+@pytest.fixture(scope='module')
+def s30():
+    """The bench workload: BASELINE.md section 3 audio, seed 0 -> [2, 1323000] -> 1292 frames."""
+    wave = separator.synth_wave(30.0, seed=0)
+    spec = stft_np.wave_to_spectrogram(wave, HOP, N_FFT)
+    assert spec.shape == (2, 1025, 1292)
+    return wave, spec
+
+
+@pytest.fixture(scope='module')
+def s30_oracle(full, s30):
+    """Oracle masks / stems / waves of the S30 song, plain and --tta, computed once (about 20 s of CPU)."""
+    _, sd = full
+    wave, spec = s30
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    out = {}
+    for tta in (False, True):
+        mask = (separator.separate_tta_mask if tta else separator.separate_mask)(spec, sd, n_fft=N_FFT, batchsize=4,
+                                                                                  cropsize=CROP)
+        y, v = separator.postprocess(spec, mask)
+        out[tta] = dict(mask=np.asarray(mask), y=y.astype(np.complex64), v=v.astype(np.complex64),
+                        yw=stft_np.spectrogram_to_wave(y.astype(np.complex64), HOP),
+                        vw=stft_np.spectrogram_to_wave(v.astype(np.complex64), HOP))
+    return out
+
+
+def _mask_error(y_got, y_want, spec):
+    """|mask_got - mask_want| recovered from the instrument stems (y = mask * X) where |X| is not tiny."""
+    mag = np.abs(spec)
+    sel = mag > 1e-2 * mag.max()
+    d = np.abs(y_got - y_want)[sel] / mag[sel]
+    return float(d.max()), float(d.mean()), float(sel.mean())
+
+
+@pytest.mark.parametrize('tta', [False, True], ids=['configs1', 'configs2_tta'])
+def test_s30_full_net_separate_wave_vs_oracle(vr, full, s30, s30_oracle, tta):
+    model, _ = full
+    wave, spec = s30
+    want = s30_oracle[tta]
+    model.set_option('serial_exec', 0)
+    sp = vr.inference.Separator(model, torch.device('cuda:0'), batchsize=0, cropsize=CROP)      # the benched executor
+    # spectrogram-level stems (and through them the mask)
+    y_spec, v_spec = (sp.separate_tta if tta else sp.separate)(spec)
+    scale = float(np.abs(spec).max())
+    assert np.abs(y_spec - want['y']).max() < 1e-4 * scale and np.abs(v_spec - want['v']).max() < 1e-4 * scale
+    mmax, mmean, cover = _mask_error(y_spec, want['y'], spec)
+    print('S30 %s: mask max-abs %.3e mean-abs %.3e over %.0f%% of the bins' % ('tta' if tta else 'plain', mmax, mmean, 100 * cover))
+    assert mmax < 1e-4 and mmean < 1e-5 and cover > 0.5
+    assert np.abs(y_spec + v_spec - spec).max() < 1e-5 * scale            # the stems sum back to the mixture
+    # wave-level, one device-resident call on a device tensor: exactly what bench.py times
+    yw, vw = sp.separate_wave(torch.from_numpy(wave).to('cuda:0'), tta=tta)
+    yw, vw = yw.cpu().numpy(), vw.cpu().numpy()
+    assert yw.shape == want['yw'].shape == (2, HOP * 1291)
+    wscale = float(np.abs(wave).max())
+    print('S30 %s: wave err y %.3e v %.3e (scale %.3f)' % ('tta' if tta else 'plain', np.abs(yw - want['yw']).max(),
+                                                          np.abs(vw - want['vw']).max(), wscale))
+    assert np.abs(yw - want['yw']).max() < 1e-4 * wscale and np.abs(vw - want['vw']).max() < 1e-4 * wscale
+    assert np.abs(yw + vw - wave[:, :yw.shape[1]]).max() < 2e-5 * wscale   # istft(stft(x)) round trip of the two stems
+
+
+@pytest.mark.parametrize('tta', [False, True], ids=['configs1', 'configs2_tta'])
+def test_s30_concurrent_executor_is_race_free(vr, full, s30, tta):
+    """Lanes, band fork and side-stream launches only reorder independent kernels: the result must equal the one
+    of the same kernels issued on ONE stream, and must not change from run to run."""
+    model, _ = full
+    wave, _ = s30
+    wd = torch.from_numpy(wave).to('cuda:0')
+    sp = vr.inference.Separator(model, torch.device('cuda:0'), batchsize=0, cropsize=CROP)
+    model.set_option('serial_exec', 1)
+    ys, vs = [t.cpu().numpy() for t in sp.separate_wave(wd, tta=tta)]
+    model.set_option('serial_exec', 0)
+    runs = [[t.cpu().numpy() for t in sp.separate_wave(wd, tta=tta)] for _ in range(3)]
+    for y, v in runs:
+        assert np.abs(y - ys).max() < 1e-5 and np.abs(v - vs).max() < 1e-5
+        assert np.array_equal(y, runs[0][0]) and np.array_equal(v, runs[0][1])       # no launch-order dependence at all
+    # smaller device batches (the reference's --batchsize 4) walk the same crops
+    sp4 = vr.inference.Separator(model, torch.device('cuda:0'), batchsize=4, cropsize=CROP)
+    y4, v4 = [t.cpu().numpy() for t in sp4.separate_wave(wd, tta=tta)]
+    assert np.abs(y4 - ys).max() < 1e-5 and np.abs(v4 - vs).max() < 1e-5
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def test_full_net_train_step(vr, full):
+    """configs[3] network and crop shape, batch 2: loss, train-mode mask, BatchNorm running statistics and every
+    gradient against the fp64 CPU oracle (pinned to the reference in test_oracle_vs_reference.py).  Gradient bar as in
+    test_gpu_train.py: per tensor max(5 x the fp32 CPU oracle's own error, 3e-2) rel-L2, median and p95 within 3x of
+    the fp32 CPU oracle's -- fp32 backprop through ~100 batch-statistics BatchNorms is noisy on the CPU too; the
+    isolated kernels are pinned at 1e-4 in test_gpu_kernels.py / test_gpu_train.py."""
+    model, sd = full
+    B, T = 2, 256
+    X, y = train_step.synth_batch(B, T=T, n_fft=N_FFT, seed=0)
+    masks = train_step.dropout_masks(B, seed=9, nout=32)
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    loss64, g64 = train_step.loss_and_grads(sd64, X.double(), y.double(), n_fft=N_FFT,
+                                            dropout={k: v.double() for k, v in masks.items()})
+    sd32 = weights.clone_state_dict(sd)
+    loss32, g32 = train_step.loss_and_grads(sd32, X, y, n_fft=N_FFT, dropout=masks)
+    try:
+        model.load_state_dict(sd)
+        model.train()
+        model.set_dropout_masks(masks)
+        model.zero_grad()
+        loss, mask = model.train_step(X.to('cuda:0'), y.to('cuda:0'), 1, return_mask=True)
+        grads = model.grads()
+        state = model.state_dict()
+    finally:
+        model.set_dropout_masks(None)
+        model.load_state_dict(sd)
+        model.eval()
+    assert abs(loss - loss64) < 2e-6, (loss, loss64)
+    report, bad = [], []
+    for k in g64:
+        if k.endswith('dense.0.bias'):
+            assert float(grads[k].abs().max()) < 1e-6, k           # exact gradient 0: a BatchNorm follows the bias
+            continue
+        e_gpu, e_cpu = _rel(grads[k], g64[k]), _rel(g32[k], g64[k])
+        report.append((e_gpu, e_cpu, k))
+        tol = max(5 * e_cpu, 3e-2) if g64[k].numel() >= 16 else max(8 * e_cpu, 0.5)
+        if e_gpu > tol:
+            bad.append('%s gpu %.3e cpu-fp32 %.3e' % (k, e_gpu, e_cpu))
+    report.sort(reverse=True)
+    print('\n'.join('%-60s gpu %.3e  cpu32 %.3e' % (k, a, b) for a, b, k in report[:15]))
+    med = float(np.median([r[0] for r in report])), float(np.median([r[1] for r in report]))
+    p95 = float(np.percentile([r[0] for r in report], 95)), float(np.percentile([r[1] for r in report], 95))
+    print('full net [2,2,1025,256]: loss %.8f (fp64 oracle %.8f); median rel-L2 gpu %.3e cpu32 %.3e; p95 gpu %.3e cpu32 %.3e'
+          % (loss, loss64, med[0], med[1], p95[0], p95[1]))
+    assert not bad, '\n'.join(bad)
+    assert med[0] < max(3 * med[1], 1e-3) and p95[0] < max(3 * p95[1], 1e-2)
+    for k in sd64:
+        if k.endswith('running_mean') or k.endswith('running_var'):
+            scale = float(sd64[k].abs().max()) + 1e-6
+            assert float((state[k].double() - sd64[k]).abs().max()) < 1e-4 * scale, k
+    sdm = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    want_mask = cascaded_net.forward(X.double(), sdm, n_fft=N_FFT, training=True, update_running=False,
+                                     dropout={k: v.double() for k, v in masks.items()})
+    assert float((mask.cpu().double() - want_mask).abs().max()) < 1e-4
+
+
+# ---- small net: fixtures generated from the reference itself ---------------------------------------------------
+@pytest.fixture(scope='module')
+def small(vr):
+    sd = weights.make_state_dict(11, n_fft=512, nout=8, nout_lstm=32)
+    wsum = sum(float(v.double().abs().sum()) for v in sd.values() if v.is_floating_point())
+    assert abs(wsum - float(GV['wsum'])) < 1e-6 * float(GV['wsum'])
+    model = vr.nets.CascadedNet(512, 256, 8, 32)
+    model.load_state_dict(sd)
+    model.to(torch.device('cuda:0'))
+    return model, sd
+
+
+def test_validate_epoch_value_vs_reference_fixture(vr, small):
+    """train.validate_epoch (train.py:108-134) on 5 samples in batches of 2 (ragged tail): the epoch value and every
+    per-batch L1 equal the reference's own numbers; forward, crop_center and the reduction run in the library."""
+    from vocal_remover_amd import train as vtrain
+    model, sd = small
+    model.load_state_dict(sd)
+    X, y = train_step.synth_batch(5, T=160, n_fft=512, seed=21)
+    dl = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(X, y), batch_size=2, shuffle=False)
+    val = vtrain.validate_epoch(dl, model, torch.device('cuda:0'))
+    assert abs(val - float(GV['val_loss'])) < 2e-6, (val, float(GV['val_loss']))
+    model.eval()
+    per = [model.validate_step(Xb, yb) for Xb, yb in dl]                    # host tensors
+    per_dev = [model.validate_step(Xb.to('cuda:0'), yb.to('cuda:0')) for Xb, yb in dl]
+    assert np.abs(np.array(per) - GV['val_batch_losses']).max() < 2e-6
+    assert np.abs(np.array(per_dev) - GV['val_batch_losses']).max() < 2e-6
+    model.train()
+    with pytest.raises(ValueError):
+        model.validate_step(X[:2], y[:2])                                  # the reference validates under model.eval()
+    model.eval()
+
+
+def test_train_mode_forward_uses_and_updates_batch_statistics(vr, small):
+    """`model(X)` under model.train() (the default state of a fresh module): batch statistics, running-stat update,
+    num_batches_tracked += 1 -- against the reference's own output; and it keeps working around train steps."""
+    model, sd = small
+    model.load_state_dict(sd)
+    model.train()
+    model.set_dropout_masks(None)
+    X, y = train_step.synth_batch(5, T=160, n_fft=512, seed=21)
+    mask = model(X[:2].to('cuda:0')).cpu().numpy()
+    assert np.abs(mask[:, :, ::7] - GV['train_fwd_mask']).max() < 1e-4
+    after = model.state_dict()
+    for key in GV.files:
+        if key.startswith('train_fwd_after::'):
+            k = key[len('train_fwd_after::'):]
+            assert np.abs(after[k].numpy() - GV[key]).max() < 1e-4 * (np.abs(GV[key]).max() + 1e-6), k
+    assert int(after['stg1_low_band_net.0.enc1.conv.1.num_batches_tracked']) == 1
+    # a fresh handle that never saw .eval(), then a train step, then forward again
+    fresh = vr.nets.CascadedNet(512, 256, 8, 32)
+    fresh.load_state_dict(sd)
+    fresh.to(torch.device('cuda:0'))
+    fresh.set_dropout_masks(None)
+    m1 = fresh(X[:2].to('cuda:0')).cpu().numpy()
+    assert np.abs(m1 - mask).max() < 1e-6
+    fresh.load_state_dict(sd)
+    fresh.zero_grad()
+    loss = fresh.train_step(X[:2], y[:2], 1)
+    assert np.isfinite(loss)
+    m2 = fresh(X[2:4].to('cuda:0')).cpu().numpy()                            # after a train step: no stale tape / arena
+    assert np.isfinite(m2).all() and m2.shape == (2, 2, 257, 160)
+    # dropout is live by default in train mode (lib/layers.py:90): two forwards differ, eval does not
+    live = vr.nets.CascadedNet(512, 256, 8, 32)
+    live.load_state_dict(sd)
+    live.to(torch.device('cuda:0'))
+    a = live(X[:2].to('cuda:0')).cpu().numpy()
+    b = live(X[:2].to('cuda:0')).cpu().numpy()
+    assert np.abs(a - b).max() > 1e-6
+    live.eval()
+    c, d = live(X[:2].to('cuda:0')).cpu().numpy(), live(X[:2].to('cuda:0')).cpu().numpy()
+    assert np.array_equal(c, d)
+
+
+def test_separate_with_device_pointers_direct_call(vr, small):
+    """vr_separate with spec and outputs on the device (header: supported) sizes its own staging arena."""
+    model, sd = small
+    model.load_state_dict(sd)
+    model.eval()
+    nat = vr.native
+    rng = np.random.default_rng(5)
+    T = 300
+    X = (rng.standard_normal((2, 257, T)) + 1j * rng.standard_normal((2, 257, T))).astype(np.complex64)
+    sp = vr.inference.Separator(model, torch.device('cuda:0'), batchsize=0, cropsize=160)
+    want_y, want_v = sp.separate(X)
+    fresh = vr.nets.CascadedNet(512, 256, 8, 32)
+    fresh.load_state_dict(sd)
+    fresh.to(torch.device('cuda:0'))
+    fresh.eval()
+    xd = torch.from_numpy(X.view(np.float32).reshape(2, 257, T, 2).copy()).to('cuda:0')
+    yd, vd = torch.empty_like(xd), torch.empty_like(xd)
+    torch.cuda.synchronize()
+    nat.check(nat.lib().vr_separate(fresh._handle.h, xd.data_ptr(), 1, T, 0, 0, 160, yd.data_ptr(), vd.data_ptr(), 1))
+    got_y = yd.cpu().numpy().reshape(2, 257, T, 2).copy().view(np.complex64)[..., 0]
+    assert np.abs(got_y - want_y).max() < 1e-6 * np.abs(X).max()

@@ -1,0 +1,122 @@
+"""The data-parallel train step on real hardware, through the C ABI.
+
+  * the library's own RCCL communicator (vr_comm_init / vr_allreduce_grads / vr_broadcast_params) with world_size 1 on
+    the one GPU of the test box: Trainer(backend='rccl').step == the single-process step, fp32 and bf16 wire formats;
+  * two ranks sharing that GPU, gloo process group, bucket staged through the host (Trainer backend 'staged'): the
+    averaged gradients equal the reference's own gradient accumulation with accumulation_steps = 2 (train.py:91-96) run
+    through the native path in one process, rank 0's broadcast makes the replicas identical, BatchNorm running
+    statistics stay rank-local (rank r == the update from micro-batch r alone).
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import train_step, weights
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_FFT, NOUT, NL = 512, 8, 32
+
+
+def _model(vr, seed=11):
+    sd = weights.make_state_dict(seed, n_fft=N_FFT, nout=NOUT, nout_lstm=NL)
+    m = vr.nets.CascadedNet(N_FFT, N_FFT // 2, NOUT, NL)
+    m.load_state_dict(sd)
+    m.to(torch.device('cuda:0'))
+    return m, sd
+
+
+def test_rccl_world1_trainer_matches_single_process(vr):
+    from vocal_remover_amd import train as vtrain
+    X, y = train_step.synth_batch(2, T=64, n_fft=N_FFT, seed=7)
+    X, y = X.to('cuda:0'), y.to('cuda:0')
+    ref_m, _ = _model(vr)
+    ref = vtrain.Trainer(ref_m, lr=1e-3, dropout=False)                       # no exchange at all
+    losses_ref = [ref.step(X, y) for _ in range(3)]
+    want = ref_m.state_dict()
+    for wire in ('fp32', 'bf16'):
+        m, _ = _model(vr)
+        tr = vtrain.Trainer(m, lr=1e-3, world_size=1, rank=0, dropout=False, backend='rccl', wire=wire)
+        assert tr.backend == 'rccl'
+        losses = [tr.step(X, y) for _ in range(3)]
+        got = m.state_dict()
+        if wire == 'fp32':                                                   # a 1-rank SUM is the identity: bit equal
+            assert losses == losses_ref
+            for k in want:
+                assert torch.equal(got[k], want[k]), k
+        else:                                                                # gradients rounded to bf16 on the wire
+            assert abs(losses[0] - losses_ref[0]) < 1e-7 and abs(losses[2] - losses_ref[2]) < 1e-3
+            for k in want:
+                if want[k].is_floating_point():
+                    assert float((got[k] - want[k]).abs().max()) <= 1e-2, k      # a few Adam steps of lr = 1e-3 apart at most
+
+
+def test_broadcast_params_world1_is_identity_and_keeps_counters(vr):
+    from vocal_remover_amd import train as vtrain
+    m, sd = _model(vr)
+    vtrain.comm_init(m, 0, 1)
+    nat = vr.native
+    nat.check(nat.lib().vr_broadcast_params(m._handle.h, 0, 1))
+    m._host_stale = True
+    got = m.state_dict()
+    for k in sd:
+        assert torch.equal(got[k], sd[k]), k
+    with pytest.raises(ValueError):
+        nat.check(nat.lib().vr_broadcast_params(m._handle.h, 3, 0))           # root out of range
+    nat.check(nat.lib().vr_comm_destroy(m._handle.h))
+    with pytest.raises(ValueError):
+        nat.check(nat.lib().vr_allreduce_grads(m._handle.h, 0))               # no communicator
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_ranks_on_one_gpu_equal_gradient_accumulation(vr, tmp_path):
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'dp_worker.py'), str(tmp_path)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    ranks = [np.load(str(tmp_path / ('rank%d.npz' % i))) for i in range(2)]
+    # the reference's semantics through the native path, one process: two micro-batches, accumulation_steps = 2
+    m, sd = _model(vr)
+    m.train()
+    m.set_dropout_masks(None)
+    X, y = train_step.synth_batch(4, T=64, n_fft=N_FFT, seed=7)
+    m.zero_grad()
+    l0 = m.train_step(X[:2].to('cuda:0'), y[:2].to('cuda:0'), 2)
+    after_mb0 = m.state_dict()                                               # running stats after micro-batch 0 only
+    l1 = m.train_step(X[2:].to('cuda:0'), y[2:].to('cuda:0'), 2)
+    acc = m.grads()
+    assert abs(float(ranks[0]['loss']) - l0) < 1e-7 and abs(float(ranks[1]['loss']) - l1) < 2e-6
+    worst = 0.0
+    for k, g in acc.items():
+        for r_ in ranks:
+            d = float(np.abs(r_['g::' + k] - g.numpy()).max())
+            s = float(g.abs().max()) + 1e-12
+            worst = max(worst, d / s)
+            assert d <= 2e-3 * s + 1e-9, (k, d, s)          # same kernels; only (g0+g1)/2 vs g0/2+g1/2 and BN stats of mb1
+    print('DP(2 ranks, staged gloo) vs accumulation_steps=2: worst gradient max-abs/scale = %.3e' % worst)
+    # the replicas hold identical parameters after the step (same averaged gradient, same Adam)
+    for k in sd:
+        if k.endswith('running_mean') or k.endswith('running_var') or k.endswith('num_batches_tracked'):
+            continue
+        assert np.array_equal(ranks[0]['p::' + k], ranks[1]['p::' + k]), k
+    # BatchNorm running statistics are rank-local: rank 0 saw micro-batch 0 only (SURVEY section 8e caveat)
+    for k in sd:
+        if k.endswith('running_mean') or k.endswith('running_var'):
+            want = after_mb0[k].numpy()
+            assert np.abs(ranks[0]['p::' + k] - want).max() <= 1e-6 * (np.abs(want).max() + 1e-6), k
+    assert int(ranks[1]['p::stg1_low_band_net.0.enc1.conv.1.num_batches_tracked']) == 1

@@ -142,7 +142,6 @@ int vr_separate(vr_handle h, const float* spec, int spec_on_device, int T, int t
     NEED(h);
     return guard([&] {
         VR_CHECK(spec && y_spec && v_spec, VR_ERR_BAD_ARGUMENT, "null argument");
-        VR_CHECK((spec_on_device != 0) == (out_on_device != 0) || true, VR_ERR_BAD_ARGUMENT, "");
         h->m.separate_api(spec, spec_on_device != 0, T, tta, batchsize, cropsize, y_spec, v_spec, out_on_device != 0);
     });
 }
@@ -211,6 +210,50 @@ int vr_grad_arena(vr_handle h, float** device_ptr, int64_t* numel) {
     return guard([&] {
         VR_CHECK(device_ptr && numel, VR_ERR_BAD_ARGUMENT, "null argument");
         h->m.grad_arena(device_ptr, numel);
+    });
+}
+
+int vr_validate_step(vr_handle h, const float* X, const float* y, int on_device, int B, int T, float* loss_out) {
+    NEED(h);
+    return guard([&] {
+        VR_CHECK(X && y, VR_ERR_BAD_ARGUMENT, "null argument");
+        h->m.validate_api(X, y, on_device != 0, B, T, loss_out);
+    });
+}
+
+int vr_comm_unique_id(void* id_out) {
+    return guard([&] {
+        VR_CHECK(id_out, VR_ERR_BAD_ARGUMENT, "null argument");
+        vr::comm_unique_id(id_out);
+    });
+}
+
+int vr_comm_init(vr_handle h, int rank, int world_size, const void* id) {
+    NEED(h);
+    return guard([&] { h->m.comm_init(rank, world_size, id); });
+}
+
+int vr_comm_destroy(vr_handle h) {
+    NEED(h);
+    return guard([&] { h->m.comm_destroy(); });
+}
+
+int vr_allreduce_grads(vr_handle h, int wire_dtype) {
+    NEED(h);
+    return guard([&] { h->m.allreduce_grads(wire_dtype); });
+}
+
+int vr_broadcast_params(vr_handle h, int root, int with_optimizer) {
+    NEED(h);
+    return guard([&] { h->m.broadcast_params(root, with_optimizer != 0); });
+}
+
+int vr_debug_kernel(vr_handle h, const char* name, const int64_t* dims, int ndims, const float* fparams, int nfparams,
+                    const float* const* inputs, int ninputs, float* const* outputs, int noutputs) {
+    NEED(h);
+    return guard([&] {
+        VR_CHECK(name && dims && inputs && outputs, VR_ERR_BAD_ARGUMENT, "null argument");
+        h->m.debug_kernel(name, dims, ndims, fparams, nfparams, inputs, ninputs, outputs, noutputs);
     });
 }
 

@@ -531,6 +531,28 @@ void launch_adam(float* p, const float* g, float* m, float* v, long long n, floa
     VR_HIP(hipGetLastError());
 }
 
+// bf16 wire format of the gradient bucket (round-to-nearest-even; NaN stays NaN)
+__global__ void f32_to_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned u = __float_as_uint(x[i]);
+    const unsigned r = ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu)) ? (u | 0x00400000u) : u + 0x7FFFu + ((u >> 16) & 1u);
+    y[i] = (unsigned short)(r >> 16);
+}
+__global__ void bf16_to_f32_kernel(const unsigned short* __restrict__ x, float* __restrict__ y, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    y[i] = __uint_as_float((unsigned)x[i] << 16);
+}
+void launch_f32_to_bf16(const float* x, unsigned short* y, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n);
+    VR_HIP(hipGetLastError());
+}
+void launch_bf16_to_f32(const unsigned short* x, float* y, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n);
+    VR_HIP(hipGetLastError());
+}
+
 // sum over (n, w) per channel of d [N][C][W]  ->  out[c]      (bias gradients)
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ d, int N, int C, int W,
                                                           float* __restrict__ out, int accumulate) {

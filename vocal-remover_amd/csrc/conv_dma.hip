@@ -371,12 +371,8 @@ template <int KS, int S, int DH, int DW, int MT, int TH, int TW, int CK, bool TM
 static void dma_launch(const ConvArgs& a, hipStream_t st) {
     using Cfg = DmaCfg<KS, S, DH, DW, MT, TH, TW, CK>;
     auto kern = conv_dma_kernel<KS, S, DH, DW, MT, TH, TW, CK, TM>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        VR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   Cfg::LDS_BYTES));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};          // per device (bit = device index)
+    ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
     const int groups = (a.npt + 7) / 8;
     const int grid = groups * 8 * a.nct;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::LDS_BYTES, st, a);

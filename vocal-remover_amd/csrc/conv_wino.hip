@@ -342,12 +342,8 @@ template <int MT>
 static void wino_launch(const ConvArgs& a, hipStream_t st) {
     using Cfg = WinoCfg<MT>;
     auto kern = conv_wino_kernel<MT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        VR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   Cfg::LDS_BYTES));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};          // per device (bit = device index)
+    ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
     const int groups = (a.npt + 7) / 8;
     const int grid = groups * 8 * a.nct;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), Cfg::LDS_BYTES, st, a);

@@ -285,12 +285,8 @@ template <int KS, int S, int MT, int TH, int TW, int CK, int NPW = 4>
 static void ws_launch(const ConvArgs& a, hipStream_t st) {
     using Cfg = WsCfg<KS, S, MT, TH, TW, CK, NPW>;
     auto kern = conv_ws_kernel<KS, S, MT, TH, TW, CK, NPW>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        VR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   Cfg::LDS_BYTES));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};          // per device (bit = device index)
+    ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
     const int groups = (a.npt + 7) / 8;
     const int grid = groups * 8 * a.nct;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, a);

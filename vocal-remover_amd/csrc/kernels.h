@@ -104,6 +104,8 @@ void launch_flip_transpose(const FlipDesc* d_descs, int n, hipStream_t st);
 void launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
                  long long step, float gscale, hipStream_t st);
 void launch_channel_sum(const float* d, int N, int C, int W, float* out, int accumulate, hipStream_t st);
+void launch_f32_to_bf16(const float* x, unsigned short* y, long long n, hipStream_t st);
+void launch_bf16_to_f32(const unsigned short* x, float* y, long long n, hipStream_t st);
 
 // ---- stft.hip -----------------------------------------------------------------------------------
 struct FFTPlan { int n_fft; int log2n; float2* twiddle; float* window; };

@@ -138,12 +138,8 @@ void launch_bilstm_train(const float* gx, const float* whh_f, const float* whh_r
     const int threads = ((G + 63) / 64) * 64;
     const size_t lds = (size_t)(H * G + H + G) * sizeof(float);
     VR_CHECK(lds <= 160 * 1024, -2, "LSTM W_hh does not fit LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        VR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bilstm_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};          // per device (bit = device index)
+    ensure_lds_attr(attr_done, reinterpret_cast<const void*>(bilstm_kernel), 160 * 1024);
     hipLaunchKernelGGL(bilstm_kernel, dim3(N, 2), dim3(threads), lds, st, gx, whh_f, whh_r, out, save, T, H);
     VR_HIP(hipGetLastError());
 }
@@ -289,12 +285,8 @@ void launch_bilstm_bwd(const float* dh, const float* save, const float* whh_f, c
     const int threads = ((G + 63) / 64) * 64;
     const size_t lds = (size_t)(G * H + G + H + 4 * H) * sizeof(float);
     VR_CHECK(G <= 1024 && lds <= 160 * 1024, -2, "LSTM hidden size too large for the LDS-resident backward");
-    static bool attr_set = false;
-    if (!attr_set) {
-        VR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bilstm_bwd_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};          // per device (bit = device index)
+    ensure_lds_attr(attr_done, reinterpret_cast<const void*>(bilstm_bwd_kernel), 160 * 1024);
     hipLaunchKernelGGL(bilstm_bwd_kernel, dim3(N, 2), dim3(threads), lds, st, dh, save, whh_f, whh_r, dgx, T, H);
     VR_HIP(hipGetLastError());
 }

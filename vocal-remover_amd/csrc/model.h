@@ -85,6 +85,8 @@ struct BaseNetL {
     LSTMMod lstm;
 };
 
+void comm_unique_id(void* out128);                       // ncclGetUniqueId (comm.hip)
+
 // host half of spec_utils.merge_artifacts (lib/spec_utils.py:60-93): per-frame mask minimum -> blend weight
 void merge_artifacts_weight(const std::vector<float>& fmin, std::vector<float>& weight, float thres, int min_range,
                             int fade);
@@ -105,18 +107,26 @@ public:
     void get_param(const std::string& key, void* host, int64_t cap_bytes);
     void set_training(bool t);
     bool training = false;
+    bool fwd_only = false;                               // train-mode vr_forward: batch statistics, no tape, no gradient buffers
+    bool taping() const { return training && !fwd_only; }
 
     // ---- forward over host or device input ----
     // x: [B,2,output_bin,T] fp32 magnitudes.  mode 0: forward (full width), 1: predict_mask
     // (offset crop), 2: predict (x*mask, offset crop).  out sized accordingly.
     void forward_api(const float* x, bool x_on_device, int B, int T, int mode, float* out, bool out_on_device);
 
+    // train.validate_epoch body for one batch (train.py:117-127): predict + crop_center(y) + L1, on the device
+    void validate_api(const float* X, const float* Y, bool on_dev, int B, int T, float* loss_out);
+    // tests only: one kernel of the training path, host pointers (debug.hip)
+    void debug_kernel(const std::string& name, const int64_t* dims, int ndims, const float* fp, int nfp,
+                      const float* const* in, int nin, float* const* out, int nout);
+
     // ---- signal path ----
     void stft_api(const float* wave, bool on_dev, long long L, float* spec, bool spec_on_dev);
     void istft_api(const float* spec, bool on_dev, int T, float* wave, bool wave_on_dev);
     // spec [2,bins,T] complex64 -> y_spec, v_spec (same shape)
     void separate_api(const float* spec, bool on_dev, int T, int tta, int batchsize, int cropsize,
-                      float* y_spec, float* v_spec, bool out_on_dev);
+                      float* y_spec, float* v_spec, bool out_on_dev, bool io_reserved = false);
     // wave [2,L] -> y_wave, v_wave [2, hop*(T-1)]: whole inference.py pipeline, device resident
     void separate_wave_api(const float* wave, bool on_dev, long long L, int tta, int batchsize, int cropsize,
                            float* y_wave, float* v_wave, bool out_on_dev);
@@ -137,6 +147,7 @@ public:
                      int B, int T, int bins, bool in_on_dev, float* Xmag, float* ymag, bool out_on_dev);
     char* aug_buf = nullptr; size_t aug_cap = 0;         // staging of the training input pipeline
     bool train_wino = true;                              // vr_set_option("train_winograd"): Winograd kernels in train mode
+    bool serial = false;                                 // vr_set_option("serial_exec"): no lanes / side streams (tests: race detector)
     void set_option(const std::string& name, int value);
     void reset_adam_state();
     void profile_end(double* conv_ms, double* conv_flops, double* conv_bytes, int* launches);
@@ -233,8 +244,10 @@ private:
     void bwd_conv(TapeRec& r);
     void bwd_bn_of(const Tensor& out, Conv& L);
     std::vector<float> dropout_host;                     // injected keep-masks [5][N][8*nout] or empty
-    int dropout_mode = 0;                                // 0 off, 1 native RNG, 2 injected
-    unsigned long long dropout_seed = 0;
+    int dropout_mode = 1;                                // 0 off, 1 native RNG (default: nn.Dropout2d is active in train mode), 2 injected
+    unsigned long long dropout_seed = 0x5DEECE66Dull;
+    unsigned long long train_calls = 0;                  // counter of train-mode forwards: a fresh dropout draw for each (lib/layers.py:90)
+    void prepare_dropout(int B);                         // fills dropout_dev for a train-mode forward of batch B
     float* dropout_buf = nullptr; size_t dropout_cap = 0;
 public:
     // train.py:77-96: forward (train mode) + L1 loss + backward; gradients accumulate in the arena.
@@ -245,6 +258,13 @@ public:
     void get_grad(const std::string& key, float* host, int64_t cap_bytes);
     void set_dropout(int mode, unsigned long long seed, const float* masks, int B);
     void grad_arena(float** ptr, int64_t* numel);
+    // ---- data-parallel exchange (comm.hip): RCCL on the handle's stream ----
+    void comm_init(int rank, int world, const void* id128);
+    void comm_destroy();
+    void allreduce_grads(int wire_dtype);
+    void broadcast_params(int root, bool with_optimizer);
+    void* comm = nullptr; int comm_rank = 0, comm_world = 1;
+    void* wire_buf = nullptr;                            // bf16 copy of the gradient bucket (wire_dtype 1)
 private:
     void build_fwd_args(Conv& L, const std::vector<SrcSpec>& srcs, int N, bool batch_as_h, ConvArgs& a);
     Tensor run_conv(Conv& L, const std::vector<SrcSpec>& srcs, int N, const Tensor* out_view, const float* bias,

@@ -125,7 +125,7 @@ Model::Model(int device_, int n_fft_, int hop_, int nout_, int nout_lstm_)
     max_bin = n_fft / 2;
     output_bin = n_fft / 2 + 1;
     VR_CHECK((max_bin / 2) % 16 == 0, -2, "n_fft/4 must be a multiple of 16 (four stride-2 encoders)");
-    VR_HIP(hipSetDevice(device));
+    DeviceGuard dev_guard(device);
     VR_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     if (!getenv("VR_NO_SIDE_STREAM")) {
         VR_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
@@ -233,7 +233,12 @@ void Model::finalize_layout() {
 }
 
 Model::~Model() {
+    int prev_dev = -1;
+    if (hipGetDevice(&prev_dev) != hipSuccess) prev_dev = -1;
     hipSetDevice(device);
+    struct Back { int d; ~Back() { if (d >= 0) hipSetDevice(d); } } back{prev_dev};
+    try { comm_destroy(); } catch (...) {}
+    hipFree(wire_buf);
     if (stream) hipStreamSynchronize(stream);
     hipFree(p_arena); hipFree(b_arena); hipFree(d_fold);
     hipFree(ws.base); hipFree(io.base); hipFree(gs.base); hipFree(wino_arena); hipFree(winot_arena); hipFree(aug_buf);
@@ -258,7 +263,7 @@ void Model::set_param(const std::string& key, const void* host, const int64_t* s
     Param& p = *it->second;
     VR_CHECK((size_t)ndim == p.shape.size(), -2, "shape rank mismatch for " + key);
     for (int i = 0; i < ndim; ++i) VR_CHECK(shape[i] == p.shape[i], -2, "shape mismatch for " + key);
-    VR_HIP(hipSetDevice(device));
+    DeviceGuard dev_guard(device);
     VR_HIP(hipStreamSynchronize(stream));
     if (p.kind == PK_NBT) { p.nbt = *static_cast<const int64_t*>(host); return; }
     const float* src = static_cast<const float*>(host);
@@ -285,7 +290,7 @@ void Model::get_param(const std::string& key, void* host, int64_t cap_bytes) {
     auto it = by_key.find(key);
     VR_CHECK(it != by_key.end(), -2, "unknown parameter key: " + key);
     Param& p = *it->second;
-    VR_HIP(hipSetDevice(device));
+    DeviceGuard dev_guard(device);
     VR_HIP(hipStreamSynchronize(stream));
     if (p.kind == PK_NBT) {
         VR_CHECK(cap_bytes >= 8, -2, "buffer too small");
@@ -328,6 +333,7 @@ void Model::fold_eval_affines() {
 
 void Model::set_option(const std::string& name, int value) {
     if (name == "train_winograd") train_wino = value != 0;
+    else if (name == "serial_exec") serial = value != 0;     // every kernel on the handle's one stream (race detector of the tests)
     else if (name == "adam_reset") reset_adam_state();      // a freshly constructed torch.optim.Adam has no moments
     else throw Error(-2, "unknown option: " + name);
 }
@@ -413,6 +419,7 @@ void Model::profile_begin() {
 }
 
 void Model::profile_end(double* conv_ms, double* conv_flops, double* conv_bytes, int* launches) {
+    DeviceGuard dev_guard(device);
     VR_HIP(hipStreamSynchronize(stream));
     double cm = 0, cf = 0, om = 0, cb = 0;
     int n = 0;
@@ -439,6 +446,7 @@ void Model::tap(const std::string& name, const Tensor& t) {
 }
 
 int64_t Model::get_tap(const std::string& name, float* host, int64_t cap_floats, int64_t* shape4) {
+    DeviceGuard dev_guard(device);
     auto it = taps.find(name);
     VR_CHECK(it != taps.end(), -2, "no such tap: " + name);
     const Tensor& t = it->second;
@@ -563,7 +571,7 @@ Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs_in, int N, cons
         if (out_view) { o.p = out_view->p; o.g = out_view->g; o.sN = out_view->sN; o.sC = out_view->sC; o.sH = out_view->sH; }
         else {
             o.p = ws.allocf((size_t)N * L.Cout * a.Wout); o.sN = (long long)L.Cout * a.Wout; o.sC = a.Wout; o.sH = a.Wout;
-            if (training) o.g = gs.allocf((size_t)N * L.Cout * a.Wout);
+            if (taping()) o.g = gs.allocf((size_t)N * L.Cout * a.Wout);
         }
         a.dst[0] = ConvDst{o.p, 0, o.sC, o.sN, 0};
     } else {
@@ -574,7 +582,7 @@ Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs_in, int N, cons
         } else {
             o.p = ws.allocf((size_t)N * L.Cout * a.Hout * a.Wout);
             o.sH = a.Wout; o.sC = (long long)a.Hout * a.Wout; o.sN = o.sC * L.Cout;
-            if (training) o.g = gs.allocf((size_t)N * L.Cout * a.Hout * a.Wout);
+            if (taping()) o.g = gs.allocf((size_t)N * L.Cout * a.Hout * a.Wout);
         }
         a.dst[0] = ConvDst{o.p, o.sN, o.sC, o.sH, 0};
     }
@@ -611,7 +619,7 @@ Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs_in, int N, cons
         }
     }
     if (L.bn && !fuse_epi) { o.aff0 = L.bn->affine; o.slope = L.slope; } else { o.aff0 = nullptr; o.slope = 1.f; }
-    if (training) {
+    if (taping()) {
         TapeRec r;
         r.kind = TK_CONV; r.L = &L; r.srcs = srcs; r.out = o; r.N = N; r.batch_as_h = batch_as_h; r.bias = bias;
         tape.push_back(std::move(r));
@@ -645,7 +653,7 @@ Tensor Model::run_lstm(LSTMMod& M, const Tensor& h) {
     zt.p = z; zt.N = N; zt.C = nb; zt.H = 1; zt.W = nf;
     zt.sN = (long long)nb * nf; zt.sC = nf; zt.sH = nf;
     zt.aff0 = M.squeeze.bn->affine; zt.slope = 0.f;
-    if (training) {
+    if (taping()) {
         zt.g = gs.allocf((size_t)N * nb * nf);
         TapeRec r;
         r.kind = TK_SQUEEZE; r.M = &M; r.srcs = {SrcSpec{h}}; r.N = N;
@@ -661,19 +669,19 @@ Tensor Model::run_lstm(LSTMMod& M, const Tensor& h) {
     }
     Tensor gx = run_conv(M.proj, {SrcSpec{zt}}, N, nullptr, bias, true);       // [N][8H][nf]
     float* hc = ws.allocf((size_t)N * 2 * M.hid * nf);                          // [N][2H][nf]
-    float* save = training ? ws.allocf((size_t)N * 2 * nf * 5 * M.hid) : nullptr;
+    float* save = taping() ? ws.allocf((size_t)N * 2 * nf * 5 * M.hid) : nullptr;
     if (!dry) launch_bilstm_train(gx.p, M.whh_f->dev, M.whh_r->dev, hc, save, N, nf, M.hid, stream);
     Tensor ht;
     ht.p = hc; ht.N = N; ht.C = 2 * M.hid; ht.H = 1; ht.W = nf;
     ht.sN = (long long)2 * M.hid * nf; ht.sC = nf; ht.sH = nf; ht.slope = 1.f;
-    if (training) {
+    if (taping()) {
         ht.g = gs.allocf((size_t)N * 2 * M.hid * nf);
         TapeRec r;
         r.kind = TK_LSTM; r.M = &M; r.N = N; r.out = ht; r.aux = gx; r.save = save;
         tape.push_back(std::move(r));
     }
     Tensor lin = run_conv(M.dense, {SrcSpec{ht}}, N, nullptr, M.dense_b->dev, true);   // [N][nb][nf] raw
-    if (training) tape.back().bias_param = M.dense_b;
+    if (taping()) tape.back().bias_param = M.dense_b;
     // BatchNorm1d + ReLU (lib/layers.py:120-121).  Eval: in place.  Train: the raw values are what the
     // BatchNorm backward needs, so the activated copy goes to its own buffer and shares lin's gradient.
     float* act = training ? ws.allocf((size_t)N * nb * nf) : lin.p;
@@ -719,7 +727,7 @@ Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, co
     Tensor pt;
     pt.p = pooled; pt.N = N; pt.C = C8; pt.H = 1; pt.W = x5.W;
     pt.sN = (long long)C8 * x5.W; pt.sC = x5.W; pt.sH = x5.W; pt.slope = 1.f;
-    if (training) {
+    if (taping()) {
         pt.g = gs.allocf((size_t)N * C8 * x5.W);
         TapeRec r;
         r.kind = TK_AVGPOOL; r.srcs = {SrcSpec{x5}}; r.out = pt; r.N = N;
@@ -731,13 +739,13 @@ Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, co
     cat4.N = N; cat4.C = 4 * C8; cat4.H = x5.H; cat4.W = x5.W;
     cat4.sH = x5.W; cat4.sC = (long long)x5.H * x5.W; cat4.sN = cat4.sC * cat4.C;
     cat4.p = ws.allocf((size_t)N * cat4.C * x5.H * x5.W);
-    if (training) cat4.g = gs.allocf((size_t)N * cat4.C * x5.H * x5.W);
+    if (taping()) cat4.g = gs.allocf((size_t)N * cat4.C * x5.H * x5.W);
     if (training) { cat4.aff0 = B.aspp_aff; cat4.slope = 0.f; }      // eval: the branch convs store final activations
     Conv* branch[4] = {&B.aspp_c2, &B.aspp_d[0], &B.aspp_d[1], &B.aspp_d[2]};
     // Eval, stage 3: the four branch convs are independent and each fills < 256 CUs at 1/16 resolution --
     // two of them go to the idle side stream.
     static const bool aspp_fork = !getenv("VR_NO_ASPP_FORK");
-    const bool afk = aspp_fork && !training && !dry && !profiling && side_stream != nullptr && !band_fork_active;
+    const bool afk = aspp_fork && !serial && !training && !dry && !profiling && side_stream != nullptr && !band_fork_active;
     hipStream_t aspp_main = stream;
     if (afk) {
         VR_HIP(hipEventRecord(ev_fork, aspp_main));
@@ -747,7 +755,7 @@ Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, co
         Tensor v = cat4;
         v.C = C8;
         v.p = dry ? cat4.p : cat4.p + (long long)j * C8 * cat4.sC;
-        if (training && !dry) v.g = cat4.g + (long long)j * C8 * cat4.sC;
+        if (taping() && !dry) v.g = cat4.g + (long long)j * C8 * cat4.sC;
         if (afk) stream = (j & 1) ? side_stream : aspp_main;
         try { run_conv(*branch[j], {SrcSpec{x5}}, N, &v, nullptr, false); } catch (...) { stream = aspp_main; throw; }
     }
@@ -762,7 +770,7 @@ Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, co
     if (training && dropout_dev) {
         int idx = (int)(&B - nets_);
         h.post = dropout_dev + (size_t)idx * N * 8 * nout;   // [5][N][8*nout] slots, row pitch 8c
-        tape.back().out.post = h.post;                        // the bottleneck's BatchNorm backward needs it
+        if (taping()) tape.back().out.post = h.post;          // the bottleneck's BatchNorm backward needs it
     }
     tap(p + ".aspp", h);
     // decoders (lib/layers.py:51-64): upsample x2 + skip concat + conv, all inside the conv's loader
@@ -774,7 +782,7 @@ Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, co
     // Eval, stage 3 (the side stream is idle there): the x2 upsample of h (HBM-bound) runs beside the LSTM branch
     // (latency-bound); both only need h, and dec1 needs both.
     static const bool lstm_fork = !getenv("VR_NO_LSTM_FORK");
-    const bool fk = lstm_fork && !training && !dry && !profiling && side_stream != nullptr && !band_fork_active;
+    const bool fk = lstm_fork && !serial && !training && !dry && !profiling && side_stream != nullptr && !band_fork_active;
     SrcSpec uh;
     if (fk) {
         hipStream_t ms = stream;
@@ -806,7 +814,7 @@ Tensor Model::run_net(const Tensor& x) {
         t.N = B; t.C = C; t.H = max_bin; t.W = T;
         t.sH = T; t.sC = (long long)max_bin * T; t.sN = t.sC * C;
         t.p = ws.allocf((size_t)B * C * max_bin * T);
-        if (training) t.g = gs.allocf((size_t)B * C * max_bin * T);
+        if (taping()) t.g = gs.allocf((size_t)B * C * max_bin * T);
         t.slope = training ? 0.f : 1.f;     // eval: dec1 / the tail convs store final activations
         return t;
     };
@@ -823,7 +831,7 @@ Tensor Model::run_net(const Tensor& x) {
     // (not while per-kernel HIP-event timing is on: overlapping kernels would inflate each other's time)
     static const bool train_fork = !getenv("VR_NO_TRAIN_FORK");
     static const bool band_fork = !getenv("VR_NO_BAND_FORK");
-    const bool fork = band_fork && !dry && (!training || train_fork) && !profiling && side_stream != nullptr;
+    const bool fork = band_fork && !serial && !dry && (!training || train_fork) && !profiling && side_stream != nullptr;
     hipStream_t main_stream = stream;
     if (fork) {
         VR_HIP(hipEventRecord(ev_fork, main_stream));
@@ -894,14 +902,20 @@ __global__ void mul_crop_kernel(const float* __restrict__ x, float* __restrict__
 }
 
 void Model::forward_api(const float* x, bool x_on_device, int B, int T, int mode, float* out, bool out_on_device) {
-    VR_HIP(hipSetDevice(device));
+    DeviceGuard dev_guard(device);
     VR_CHECK(B > 0, -2, "batch must be positive");
     check_T(T, offset, mode);
     const size_t in_floats = (size_t)B * 2 * output_bin * T;
     const int Wm = mode == 0 ? T : T - 2 * offset;
     const size_t out_floats = (size_t)B * 2 * output_bin * Wm;
+    // Train mode (the reference's `model(X)` under model.train(), train.py:81 without the backward): BatchNorm uses
+    // and updates batch statistics, Dropout2d is live, but no tape and no gradient buffers are kept.
+    struct FwdOnly { Model* m; ~FwdOnly() { m->fwd_only = false; m->dropout_dev = nullptr; } } fwd_scope{this};
+    fwd_only = training;
+    if (training) refresh_wino(false);      // before planning: the kernel choice (and its partial-statistics layout) depends on them
     plan_and_reserve(B, T, (in_floats + out_floats) * sizeof(float) + 1024);
     if (!training) fold_eval_affines();
+    else prepare_dropout(B);
     float* xd = ws.allocf(in_floats);
     float* od = out_on_device ? out : ws.allocf(out_floats);
     if (x_on_device) VR_HIP(hipMemcpyAsync(xd, x, in_floats * sizeof(float), hipMemcpyDeviceToDevice, stream));
@@ -926,11 +940,73 @@ void Model::forward_api(const float* x, bool x_on_device, int B, int T, int mode
     if (training) affine_dirty = true;
 }
 
+// sum |pred - crop_center(y)| per block; pred [rows][Wm] dense, y [rows][T] dense, columns [off, off+Wm) of y
+__global__ __launch_bounds__(256) void l1_crop_kernel(const float* __restrict__ pred, const float* __restrict__ y, int T, int Wm,
+                                                      int off, long long total, float* __restrict__ part) {
+    float s = 0.f;
+    for (long long gid = (long long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long long)gridDim.x * 256) {
+        const int w = (int)(gid % Wm);
+        const long long row = gid / Wm;
+        s += fabsf(pred[gid] - y[row * T + off + w]);
+    }
+    __shared__ float red[4];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// One batch of train.validate_epoch (train.py:117-127): y_pred = model.predict(X); y = crop_center(y, y_pred);
+// loss = L1Loss()(y_pred, y) -- forward, crop and the mean-absolute-error reduction all on the device.
+void Model::validate_api(const float* X, const float* Y, bool on_dev, int B, int T, float* loss_out) {
+    DeviceGuard dev_guard(device);
+    VR_CHECK(!training, -2, "validate step runs in eval mode (train.py:109 model.eval()); call vr_set_mode(h, 0) first");
+    VR_CHECK(B > 0, -2, "batch must be positive");
+    check_T(T, offset, 2);
+    const size_t in_floats = (size_t)B * 2 * output_bin * T;
+    const int Wm = T - 2 * offset;
+    const size_t out_floats = (size_t)B * 2 * output_bin * Wm;
+    const int nblk = 1024;
+    plan_and_reserve(B, T, (2 * in_floats + out_floats + nblk + 64) * sizeof(float) + 8192);
+    fold_eval_affines();
+    float* xd = ws.allocf(in_floats);
+    const float* yd = Y;
+    const hipMemcpyKind kind = on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    VR_HIP(hipMemcpyAsync(xd, X, in_floats * sizeof(float), kind, stream));
+    if (!on_dev) {
+        float* ty = ws.allocf(in_floats);
+        VR_HIP(hipMemcpyAsync(ty, Y, in_floats * sizeof(float), hipMemcpyHostToDevice, stream));
+        yd = ty;
+    }
+    float* od = ws.allocf(out_floats);
+    float* part = ws.allocf(nblk);
+    float* lossd = ws.allocf(16);
+    Tensor xt;
+    xt.p = xd; xt.N = B; xt.C = 2; xt.H = max_bin; xt.W = T;
+    xt.sH = T; xt.sC = (long long)output_bin * T; xt.sN = 2 * xt.sC; xt.slope = 1.f;
+    Tensor f3 = run_net(xt);
+    HeadDst d{};
+    d.p = od; d.dH = Wm; d.dC = (long long)output_bin * Wm; d.dN = 2 * d.dC;
+    d.w_lo = offset; d.w_hi = T - offset; d.pad_rows = output_bin - max_bin;
+    launch_head_sigmoid(f3, out_w->dev, d, stream);
+    const long long total = (long long)out_floats;
+    hipLaunchKernelGGL(mul_crop_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, xd, od, T, Wm, offset, total);
+    VR_HIP(hipGetLastError());
+    hipLaunchKernelGGL(l1_crop_kernel, dim3(nblk), dim3(256), 0, stream, od, yd, T, Wm, offset, total, part);
+    VR_HIP(hipGetLastError());
+    launch_reduce_rows(part, 1, nblk, lossd, 1, 0, (float)(1.0 / (double)total), stream);
+    float loss_h = 0.f;
+    VR_HIP(hipMemcpyAsync(&loss_h, lossd, sizeof(float), hipMemcpyDeviceToHost, stream));
+    VR_HIP(hipStreamSynchronize(stream));
+    if (loss_out) *loss_out = loss_h;
+}
+
 // =====================================================================================================
 // signal path
 // =====================================================================================================
 void Model::stft_api(const float* wave, bool on_dev, long long L, float* spec, bool spec_on_dev) {
-    VR_HIP(hipSetDevice(device));
+    DeviceGuard dev_guard(device);
     VR_CHECK(L > 0, -2, "empty wave");
     const int T = 1 + (int)(L / hop);
     const size_t spec_f = (size_t)2 * output_bin * T * 2;
@@ -949,7 +1025,7 @@ void Model::stft_api(const float* wave, bool on_dev, long long L, float* spec, b
 }
 
 void Model::istft_api(const float* spec, bool on_dev, int T, float* wave, bool wave_on_dev) {
-    VR_HIP(hipSetDevice(device));
+    DeviceGuard dev_guard(device);
     VR_CHECK(T > 0, -2, "empty spectrogram");
     const size_t spec_f = (size_t)2 * output_bin * T * 2;
     const size_t out_f = (size_t)2 * hop * (T - 1);
@@ -1028,8 +1104,8 @@ static size_t separate_scratch_floats(int bins, int T, int cropsize, int offset,
 }
 
 void Model::separate_api(const float* spec, bool on_dev, int T, int tta, int batchsize, int cropsize, float* y_spec,
-                         float* v_spec, bool out_on_dev) {
-    VR_HIP(hipSetDevice(device));
+                         float* v_spec, bool out_on_dev, bool io_reserved) {
+    DeviceGuard dev_guard(device);
     const bool post = (tta & 2) != 0;       // flags: bit 0 = --tta, bit 1 = --postprocess
     tta &= 1;
     VR_CHECK(T > 0, -2, "empty spectrogram");
@@ -1041,8 +1117,9 @@ void Model::separate_api(const float* spec, bool on_dev, int T, int tta, int bat
     int pad_l, pad_r, roi;
     make_padding(T, cropsize, offset, pad_l, pad_r, roi);
     const size_t scratch = separate_scratch_floats(bins, T, cropsize, offset, tta);
-    if (!on_dev || !out_on_dev) {
-        // host-facing call: stage through `io` (the wave-level entry point reserves for itself)
+    if (!io_reserved) {
+        // direct call (host or device pointers): size and rewind the staging arena here; only the wave-level entry
+        // point, which has already carved its own buffers out of `io`, passes io_reserved
         ensure_io((3 * spec_f + scratch) * sizeof(float) + 65536);
         io.reset();
     }
@@ -1100,7 +1177,7 @@ void Model::separate_api(const float* spec, bool on_dev, int T, int tta, int bat
         for (int i = 0; i < patches; i += bs) {
             const int nb = std::min(bs, patches - i);
             const int K = std::min((int)lanes.size() + 1, nb);
-            if (K < 2 || profiling) {
+            if (K < 2 || profiling || serial) {
                 run_crops(i, nb);
                 continue;
             }
@@ -1158,7 +1235,7 @@ void Model::separate_api(const float* spec, bool on_dev, int T, int tta, int bat
 
 void Model::separate_wave_api(const float* wave, bool on_dev, long long L, int tta, int batchsize, int cropsize,
                               float* y_wave, float* v_wave, bool out_on_dev) {
-    VR_HIP(hipSetDevice(device));
+    DeviceGuard dev_guard(device);
     VR_CHECK(L >= hop, -2, "wave shorter than one hop");
     const int T = 1 + (int)(L / hop);
     const int bins = output_bin;
@@ -1181,7 +1258,7 @@ void Model::separate_wave_api(const float* wave, bool on_dev, long long L, int t
     float* yw = out_on_dev ? y_wave : io.allocf(out_f + 4);
     float* vw = out_on_dev ? v_wave : io.allocf(out_f + 4);
     launch_stft(plan, wd, L, hop, T, reinterpret_cast<float2*>(spec), stream);
-    separate_api(spec, true, T, tta, batchsize, cropsize, ys, vs, true);
+    separate_api(spec, true, T, tta, batchsize, cropsize, ys, vs, true, /*io_reserved=*/true);
     launch_istft(plan, reinterpret_cast<const float2*>(ys), hop, T, frames, yw, stream);
     launch_istft(plan, reinterpret_cast<const float2*>(vs), hop, T, frames, vw, stream);
     if (!out_on_dev && out_f) {
@@ -1197,7 +1274,7 @@ void Model::separate_wave_api(const float* wave, bool on_dev, long long L, int t
 void Model::debug_conv(const float* x, int N, int Cin, int H, int W, const float* w_oihw, int Cout, int KS, int stride,
                        int dh, int dw, int flags, const float* aff, float slope, const float* bias, float* out,
                        float* stats_out) {
-    VR_HIP(hipSetDevice(device));
+    DeviceGuard dev_guard(device);
     // flags: bit 0 = fused x2 upsample; bit 1 = give the launch Winograd-domain weights (conv_wino.hip);
     //        bit 2 = `aff`/`slope` describe the EPILOGUE ([Cout][2] folded BatchNorm + activation, eval mode)
     const int up = flags & 1;

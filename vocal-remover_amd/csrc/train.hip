@@ -2,7 +2,6 @@
 // (train.py:81-96: loss = L1(mask*X, y); (loss/accumulation_steps).backward(); optimizer.step()).
 #include <cmath>
 #include <cstring>
-#include <random>
 
 #include "model.h"
 
@@ -69,14 +68,14 @@ void Model::ensure_train_state() {
 }
 
 void Model::zero_grad_api() {
-    VR_HIP(hipSetDevice(device));
+    DeviceGuard dev_guard(device);
     ensure_train_state();
     VR_HIP(hipMemsetAsync(g_arena, 0, p_floats * sizeof(float), stream));
     VR_HIP(hipStreamSynchronize(stream));
 }
 
 void Model::grad_arena(float** ptr, int64_t* numel) {
-    VR_HIP(hipSetDevice(device));
+    DeviceGuard dev_guard(device);
     ensure_train_state();
     *ptr = g_arena;
     *numel = (int64_t)p_floats;
@@ -91,6 +90,44 @@ void Model::set_dropout(int mode, unsigned long long seed, const float* masks, i
         VR_CHECK(masks && B > 0, -2, "injected dropout needs masks [5][B][8*nout]");
         dropout_host.assign(masks, masks + (size_t)5 * B * 8 * nout);
     }
+}
+
+// nn.Dropout2d(0.1) keep-masks for one train-mode forward (lib/layers.py:90: the five ASPP outputs), [5][B][8*nout]
+// holding 0 or 1/0.9.  Mode 1 draws them on the device from a counter-based generator keyed on (seed, number of
+// train-mode forwards so far, element): every forward -- each micro-batch of an accumulation window too -- gets a
+// fresh draw, as torch does, and nothing restarts when the optimizer is re-created.
+__global__ void dropout_mask_kernel(float* __restrict__ m, long long n, unsigned long long seed, unsigned long long call) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long x = seed + 0x9E3779B97F4A7C15ull * (call + 1) + 0xD1B54A32D192ED03ull * (unsigned long long)(i + 1);
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;            // splitmix64 finalizer
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    const float u = (float)(x >> 40) * (1.f / 16777216.f);
+    m[i] = (u >= 0.1f) ? (1.f / 0.9f) : 0.f;
+}
+
+void Model::prepare_dropout(int B) {
+    dropout_dev = nullptr;
+    train_calls += 1;
+    if (dropout_mode == 0) return;
+    const size_t n = (size_t)5 * B * 8 * nout;
+    if (n > dropout_cap) {
+        VR_HIP(hipStreamSynchronize(stream));
+        if (dropout_buf) VR_HIP(hipFree(dropout_buf));
+        dropout_buf = nullptr; dropout_cap = 0;
+        VR_HIP(hipMalloc(&dropout_buf, n * sizeof(float)));
+        dropout_cap = n;
+    }
+    if (dropout_mode == 2) {
+        VR_CHECK(dropout_host.size() == n, -2, "injected dropout masks were given for a different batch size");
+        VR_HIP(hipMemcpyAsync(dropout_buf, dropout_host.data(), n * sizeof(float), hipMemcpyHostToDevice, stream));
+    } else {
+        hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dropout_buf, (long long)n,
+                           dropout_seed, train_calls);
+        VR_HIP(hipGetLastError());
+    }
+    dropout_dev = dropout_buf;
 }
 
 // BatchNorm backward of a conv record: G -> dz in place, d(gamma), d(beta) into the gradient arena.
@@ -135,7 +172,7 @@ void Model::bwd_conv(TapeRec& r) {
             // tails of one stream's kernels fill the other's bubbles.  backward() joins before returning.
             static const bool overlap = !getenv("VR_NO_WGRAD_OVERLAP");
             hipStream_t wst = stream;
-            if (overlap && !profiling && side_stream) {
+            if (overlap && !serial && !profiling && side_stream) {
                 VR_HIP(hipEventRecord(ev_fork, stream));          // dz (and every forward tensor) is ready here
                 VR_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
                 wst = side_stream;
@@ -256,7 +293,7 @@ void Model::backward() {
     // they come first after stage 3, so they are enqueued on a second stream and the low chain follows on the main one.
     static const bool bwd_fork = !getenv("VR_NO_BWD_FORK");
     hipStream_t main_stream = stream;
-    hipStream_t hi_stream = (bwd_fork && !dry && !profiling && !lanes.empty()) ? lanes[0].main : nullptr;
+    hipStream_t hi_stream = (bwd_fork && !serial && !dry && !profiling && !lanes.empty()) ? lanes[0].main : nullptr;
     int cur_chain = 0;
     bool hi_used = false;
     struct Restore {
@@ -326,7 +363,7 @@ void Model::backward() {
 
 void Model::train_fwd_bwd_api(const float* X, const float* Y, bool on_dev, int B, int T, int accumulation_steps,
                               float* loss_out, float* mask_out, bool mask_on_dev) {
-    VR_HIP(hipSetDevice(device));
+    DeviceGuard dev_guard(device);
     VR_CHECK(training, -2, "train step needs train mode: call vr_set_mode(h, 1) (model.train(), train.py:69)");
     VR_CHECK(B > 0 && accumulation_steps > 0, -2, "batch and accumulation_steps must be positive");
     VR_CHECK(T > 0 && T % 16 == 0, -5, "h1_shape[3] must be greater than h2_shape[3] (frames must be a multiple of 16)");
@@ -388,28 +425,7 @@ void Model::train_fwd_bwd_api(const float* X, const float* Y, bool on_dev, int B
             VR_HIP(hipMemsetAsync(gs.base, 0, need_gs, stream));
         }
     }
-    // ---- dropout keep-masks (lib/layers.py:90: Dropout2d(0.1) on the five ASPP outputs) ----------------------
-    dropout_dev = nullptr;
-    if (dropout_mode != 0) {
-        const size_t n = (size_t)5 * B * 8 * nout;
-        std::vector<float> host(n, 0.f);
-        if (dropout_mode == 2) {
-            VR_CHECK(dropout_host.size() == n, -2, "injected dropout masks were given for a different batch size");
-            host = dropout_host;
-        } else {
-            std::mt19937_64 rng(dropout_seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(adam_step + 1));
-            std::uniform_real_distribution<float> u(0.f, 1.f);
-            for (auto& v : host) v = (u(rng) >= 0.1f) ? 1.f / 0.9f : 0.f;
-        }
-        if (n > dropout_cap) {
-            if (dropout_buf) VR_HIP(hipFree(dropout_buf));
-            VR_HIP(hipMalloc(&dropout_buf, n * sizeof(float)));
-            dropout_cap = n;
-        }
-        VR_HIP(hipMemcpyAsync(dropout_buf, host.data(), n * sizeof(float), hipMemcpyHostToDevice, stream));
-        VR_HIP(hipStreamSynchronize(stream));      // `host` dies with this scope
-        dropout_dev = dropout_buf;
-    }
+    prepare_dropout(B);
     // ---- inputs ---------------------------------------------------------------------------------------------------
     const float *xd = X, *yd = Y;
     if (!on_dev) {
@@ -437,7 +453,7 @@ void Model::train_fwd_bwd_api(const float* X, const float* Y, bool on_dev, int B
 // Training input pipeline (lib/dataset.py:105-120 after the random draws and the file reads), see augment.hip.
 void Model::augment_api(const float* Xc, const float* yc, const float* Xi, const float* yi, const void* desc, const float* rw,
                         int B, int T, int bins, bool in_on_dev, float* Xmag, float* ymag, bool out_on_dev) {
-    VR_HIP(hipSetDevice(device));
+    DeviceGuard dev_guard(device);
     VR_CHECK(B > 0 && T > 0 && bins > 0, -2, "augment: empty batch");
     const size_t crop_b = (size_t)B * T * 2 * bins * sizeof(float2), out_b = (size_t)B * 2 * bins * T * sizeof(float);
     const size_t desc_b = (size_t)B * sizeof(AugDesc), rw_b = (size_t)bins * sizeof(float);
@@ -479,7 +495,7 @@ void Model::augment_api(const float* Xc, const float* yc, const float* Xi, const
 }
 
 void Model::reset_adam_state() {
-    VR_HIP(hipSetDevice(device));
+    DeviceGuard dev_guard(device);
     adam_step = 0;
     if (m_arena) {
         VR_HIP(hipMemsetAsync(m_arena, 0, p_floats * sizeof(float), stream));
@@ -489,7 +505,7 @@ void Model::reset_adam_state() {
 }
 
 void Model::adam_step_api(float lr, float b1, float b2, float eps, float grad_scale) {
-    VR_HIP(hipSetDevice(device));
+    DeviceGuard dev_guard(device);
     ensure_train_state();
     adam_step += 1;
     launch_adam(p_arena, g_arena, m_arena, v_arena, (long long)p_floats, lr, b1, b2, eps, adam_step, grad_scale, stream);
@@ -502,7 +518,7 @@ void Model::get_grad(const std::string& key, float* host, int64_t cap_bytes) {
     VR_CHECK(it != by_key.end(), -2, "unknown parameter key: " + key);
     Param& p = *it->second;
     VR_CHECK(p.trainable, -2, key + " is a buffer, it has no gradient");
-    VR_HIP(hipSetDevice(device));
+    DeviceGuard dev_guard(device);
     ensure_train_state();
     VR_HIP(hipStreamSynchronize(stream));
     VR_CHECK((size_t)cap_bytes >= p.numel * sizeof(float), -2, "buffer too small for " + key);
@@ -535,7 +551,7 @@ namespace vr {
 void Model::debug_conv_bwd(const float* x, int N, int Cin, int H, int W, const float* w_oihw, int Cout, int KS, int stride,
                            int dh, int dw, int up, const float* aff, float slope, const float* dz, float* dx_out,
                            float* dw_out) {
-    VR_HIP(hipSetDevice(device));
+    DeviceGuard dev_guard(device);
     ensure_train_state();
     const int KK = KS * KS, CoutPad = (Cout + 31) / 32 * 32, CinPad = round_up32(Cin);
     Conv L;

@@ -1,6 +1,7 @@
 // Shared declarations for libvr_mi355.so (gfx950 / MI355X only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <stdexcept>
@@ -28,6 +29,31 @@ struct Error : std::runtime_error {
     do {                                                                                          \
         if (!(cond)) throw ::vr::Error((code), (msg));                                            \
     } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device only: remember it per
+// (kernel instance, device) so that a process holding handles on several GPUs sets it on each of them.
+inline void ensure_lds_attr(std::atomic<unsigned long long>& done_mask, const void* kern, int bytes) {
+    int dev = 0;
+    VR_HIP(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done_mask.load(std::memory_order_acquire) & bit) return;
+    VR_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done_mask.fetch_or(bit, std::memory_order_release);
+}
+
+// Every API call runs on the handle's GPU and puts the caller's current device back afterwards
+// (torch keeps its own notion of the current device per thread).
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) VR_HIP(hipSetDevice(device));
+        else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 // ---------------------------------------------------------------------------------------------
 // Activation tensors in HBM.

@@ -454,12 +454,8 @@ template <int KS, int S, int DH, int DW, int TH, int TW, int MB>
 static void wg_launch_inst(const WgradArgs& a, hipStream_t st) {
     using Cfg = WgCfg<KS, S, DH, DW, TH, TW, MB>;
     auto kern = wgrad_mfma_kernel<KS, S, DH, DW, TH, TW, MB>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        VR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   Cfg::LDS_BYTES));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};          // per device (bit = device index)
+    ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
     const int grid = ((a.P + 7) / 8) * 8 * a.nchunks * a.nct;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::LDS_BYTES, st, a);
     VR_HIP(hipGetLastError());
@@ -477,12 +473,8 @@ static void wg_launch_ws_inst(const WgradArgs& a, hipStream_t st) {
     constexpr int NPW = 8;
     using Ws = WgWsCfg<KS, S, TH, TW, MB>;
     auto kern = wgrad_ws_kernel<KS, S, TH, TW, MB, NPW>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        VR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   Ws::LDS_BYTES));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};          // per device (bit = device index)
+    ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), Ws::LDS_BYTES);
     const int grid = ((a.P + 7) / 8) * 8 * a.nchunks * a.nct;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256 + 64 * NPW), Ws::LDS_BYTES, st, a);
     VR_HIP(hipGetLastError());

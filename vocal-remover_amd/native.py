@@ -41,6 +41,16 @@ _SIGNATURES = {
     'vr_augment_batch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_void_p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+    'vr_validate_step': (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.POINTER(ctypes.c_float)]),
+    'vr_comm_unique_id': (ctypes.c_int, [ctypes.c_void_p]),
+    'vr_comm_init': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'vr_comm_destroy': (ctypes.c_int, [ctypes.c_void_p]),
+    'vr_allreduce_grads': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    'vr_broadcast_params': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    'vr_debug_kernel': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_i64p, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
+                                       ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int,
+                                       ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]),
     'vr_profile_begin': (ctypes.c_int, [ctypes.c_void_p]),
     'vr_profile_end': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
                                       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int),
@@ -95,7 +105,21 @@ def check(rc):
         raise IndexError(msg)              # merge_artifacts on a mask with no frame above the threshold
     if rc == -2:
         raise ValueError(msg)
+    if rc == -8:
+        raise VRError('libvr_mi355 RCCL error: %s' % msg)
     raise VRError('libvr_mi355 error %d: %s' % (rc, msg))
+
+
+def debug_kernel(handle, name, dims, fparams, inputs, outputs):
+    """vr_debug_kernel: `inputs` / `outputs` are lists of C-contiguous float32 numpy arrays (or None)."""
+    dims_a = (ctypes.c_int64 * max(len(dims), 1))(*[int(d) for d in dims])
+    fp_a = (ctypes.c_float * max(len(fparams), 1))(*[float(f) for f in fparams])
+    ins = (ctypes.c_void_p * max(len(inputs), 1))(*[a.ctypes.data if a is not None else None for a in inputs])
+    outs = (ctypes.c_void_p * max(len(outputs), 1))(*[a.ctypes.data if a is not None else None for a in outputs])
+    for a in list(inputs) + list(outputs):
+        assert a is None or (a.flags['C_CONTIGUOUS'] and a.dtype == np.float32)
+    check(lib().vr_debug_kernel(handle.h, name.encode(), dims_a, len(dims), fp_a, len(fparams), ins, len(inputs), outs,
+                                len(outputs)))
 
 
 def np_ptr(a):

@@ -150,6 +150,10 @@ class CascadedNet(object):
                 self._device = torch.device('cuda', index)
                 self._push()
                 native.check(native.lib().vr_set_mode(self._handle.h, int(self.training)))
+                # nn.Dropout2d(0.1) on the ASPP outputs is live in train mode (lib/layers.py:90): the library's
+                # generator is seeded from torch's seed, so torch.manual_seed() makes runs repeatable
+                native.check(native.lib().vr_set_dropout(self._handle.h, 1, (torch.initial_seed() + index) & (2 ** 63 - 1),
+                                                         None, 0))
         elif device.type == 'cpu':
             self._pull()
             if self._handle is not None:
@@ -250,6 +254,26 @@ class CascadedNet(object):
         self._host_stale = True
         return (loss.value, mask) if return_mask else loss.value
 
+    def validate_step(self, X, y):
+        """One batch of train.validate_epoch (train.py:117-127): L1(predict(X), crop_center(y)) -> float."""
+        import ctypes
+        h = self._need_handle()
+        X = torch.as_tensor(X)
+        y = torch.as_tensor(y)
+        if X.shape != y.shape or X.dim() != 4 or X.shape[1] != 2 or X.shape[2] != self.output_bin:
+            raise ValueError('expected X, y of shape [B, 2, %d, T]' % self.output_bin)
+        on_dev = X.is_cuda
+        if on_dev != y.is_cuda:
+            raise ValueError('X and y must live on the same device')
+        X = X.detach().to(torch.float32).contiguous()
+        y = y.detach().to(torch.float32).contiguous()
+        if on_dev:
+            torch.cuda.current_stream(X.device).synchronize()
+        loss = ctypes.c_float()
+        native.check(native.lib().vr_validate_step(h.h, X.data_ptr(), y.data_ptr(), int(on_dev), int(X.shape[0]),
+                                                   int(X.shape[3]), ctypes.byref(loss)))
+        return loss.value
+
     def grads(self, keys=None):
         """{key: gradient} in torch layouts (param.grad of the reference), for tests."""
         h = self._need_handle()
@@ -271,7 +295,8 @@ class CascadedNet(object):
 
     def set_dropout_masks(self, masks):
         """Inject Dropout2d keep-masks {'<net>.aspp': [B, 8c] tensor of 0 / (1/0.9)} (parity tests);
-        None switches dropout off; an int seeds the library's own RNG."""
+        None switches dropout OFF (explicit opt-out: the default is on, as in the reference); an int
+        (re)seeds the library's own generator."""
         h = self._need_handle()
         if masks is None:
             native.check(native.lib().vr_set_dropout(h.h, 0, 0, None, 0))

@@ -4,8 +4,8 @@
     validate_epoch(dataloader, model, device)                               train.py:108-134
     Adam(model.parameters(), lr=...)                                        train.py:215-218
     Trainer(model, lr, world_size, rank)       data-parallel step: fwd + L1 + bwd -> all-reduce of the
-                                               single flat gradient bucket (RCCL via torch.distributed)
-                                               -> fused Adam
+                                               single flat gradient bucket (the library's own RCCL
+                                               communicator, vr_allreduce_grads) -> fused Adam
 
 The reference's sequence `mask = model(X); loss = crit(mask * X, y); (loss/acc).backward();
 optimizer.step(); model.zero_grad()` maps to vr_train_step / vr_adam_step / vr_zero_grad.
@@ -15,7 +15,6 @@ import ctypes
 import torch
 
 from . import native
-from . import spec_utils
 
 
 class _ParamRef(object):
@@ -71,32 +70,108 @@ def grad_bucket(model):
 
 def allreduce_mean_(bucket, world_size):
     """Sum-all-reduce a flat gradient bucket in place; the 1/world is folded into Adam's grad_scale.
-    Works on any backend (nccl = RCCL on the GPUs, gloo in the CPU tests)."""
+    Works on any torch.distributed backend (nccl = RCCL on the GPUs, gloo in the CPU tests)."""
     if world_size > 1:
         import torch.distributed as dist
         dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
     return 1.0 / world_size
 
 
-class Trainer(object):
+def comm_init(model, rank, world_size, exchange=None):
+    """Create the library's own RCCL communicator on the model's handle (vr_comm_init).
 
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, world_size=1, rank=0, dropout_seed=None):
+    The 128-byte ncclUniqueId travels from rank 0 to the others over a host channel: `exchange(id_bytes_or_None)
+    -> id_bytes`; default = torch.distributed.broadcast_object_list on the default process group (any backend)."""
+    h = model._need_handle()
+    buf = ctypes.create_string_buffer(128)
+    if rank == 0:
+        native.check(native.lib().vr_comm_unique_id(buf))
+    if world_size > 1:
+        if exchange is None:
+            import torch.distributed as dist
+            box = [buf.raw if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            raw = box[0]
+        else:
+            raw = exchange(buf.raw if rank == 0 else None)
+        buf = ctypes.create_string_buffer(raw, 128)
+    native.check(native.lib().vr_comm_init(h.h, int(rank), int(world_size), buf))
+
+
+class Trainer(object):
+    """Data-parallel train step of train.py:77-96: fwd + L1 + bwd on every rank's shard, ONE sum-all-reduce of the
+    flat gradient arena, fused Adam with grad_scale = 1/world.  N ranks == the reference's gradient accumulation
+    with accumulation_steps = N (per-replica BatchNorm statistics, rank-local running buffers).
+
+    backend  'rccl'   the library's own RCCL communicator (vr_allreduce_grads, on the handle's stream, no host
+                      round trip before Adam); the default on GPUs
+             'torch'  torch.distributed.all_reduce over the zero-copy view of the arena (process group = nccl)
+             'staged' the bucket is staged through host memory (process group = gloo): several ranks may then share
+                      one GPU, which is how the 2-rank path is tested on a 1-GPU box
+             'auto'   world 1: none; nccl process group: 'rccl'; gloo process group: 'staged'
+    wire     'fp32' (default) or 'bf16' (rccl backend only: the bucket crosses xGMI in bf16)
+    broadcast  rank 0's weights, BatchNorm buffers and Adam state replace everyone's at construction."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, world_size=1, rank=0, dropout_seed=None,
+                 dropout=True, backend='auto', wire='fp32', broadcast=True):
         self.model = model
         self.world_size = world_size
         self.rank = rank
         self.opt = Adam(model.parameters(), lr=lr, betas=betas, eps=eps)
         model.train()
         h = model._need_handle()
-        if dropout_seed is not None:
-            native.check(native.lib().vr_set_dropout(h.h, 1, int(dropout_seed) + rank, None, 0))
-        self._bucket = grad_bucket(model) if world_size > 1 else None
+        # Dropout2d(0.1) of the ASPP outputs (lib/layers.py:90) is ON by default (seeded from torch's seed in
+        # CascadedNet.to()); every rank draws its own stream.  dropout=False is the explicit opt-out.
+        if not dropout:
+            native.check(native.lib().vr_set_dropout(h.h, 0, 0, None, 0))
+        elif dropout_seed is not None:
+            native.check(native.lib().vr_set_dropout(h.h, 1, (int(dropout_seed) + rank) & (2 ** 63 - 1), None, 0))
+        elif rank:
+            native.check(native.lib().vr_set_dropout(h.h, 1, (torch.initial_seed() + 7919 * rank) & (2 ** 63 - 1), None, 0))
+        if backend == 'auto':
+            if world_size == 1:
+                backend = 'none'
+            else:
+                import torch.distributed as dist
+                backend = 'rccl' if dist.get_backend() == 'nccl' else 'staged'
+        if backend not in ('none', 'rccl', 'torch', 'staged'):
+            raise ValueError('unknown backend %r' % (backend,))
+        if wire not in ('fp32', 'bf16') or (wire == 'bf16' and backend != 'rccl'):
+            raise ValueError("wire must be 'fp32', or 'bf16' with backend='rccl'")
+        self.backend = backend
+        self.wire = 1 if wire == 'bf16' else 0
+        self._bucket = grad_bucket(model) if backend in ('torch', 'staged') else None
+        if backend == 'rccl':
+            comm_init(model, rank, world_size)
+            if broadcast:
+                native.check(native.lib().vr_broadcast_params(h.h, 0, 1))
+                model._host_stale = True
+        elif backend in ('torch', 'staged') and broadcast and world_size > 1:
+            import torch.distributed as dist
+            box = [model.state_dict() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            if rank != 0:
+                model.load_state_dict(box[0])
         model.zero_grad()
+
+    def reduce(self):
+        """The exchange step: SUM the gradient arena over the ranks in place; Adam's grad_scale becomes 1/world."""
+        if self.backend == 'rccl':
+            h = self.model._need_handle()
+            native.check(native.lib().vr_allreduce_grads(h.h, self.wire))       # on the handle's stream, no host sync
+        elif self.backend == 'torch':
+            allreduce_mean_(self._bucket, self.world_size)
+            torch.cuda.current_stream().synchronize()
+        elif self.backend == 'staged':
+            host = self._bucket.cpu()
+            allreduce_mean_(host, self.world_size)
+            self._bucket.copy_(host)
+            torch.cuda.current_stream().synchronize()
+        self.opt.grad_scale = 1.0 / self.world_size
 
     def step(self, X, y, accumulation_steps=1):
         loss = self.model.train_step(X, y, accumulation_steps)
-        if self._bucket is not None:
-            self.opt.grad_scale = allreduce_mean_(self._bucket, self.world_size)
-            torch.cuda.current_stream().synchronize()
+        self.reduce()
         self.opt.step()
         self.model.zero_grad()
         return loss
@@ -122,40 +197,13 @@ def train_epoch(dataloader, model, device, optimizer, accumulation_steps):
 
 
 def validate_epoch(dataloader, model, device):
-    """train.validate_epoch (train.py:108-134): eval, predict, crop_center(y), L1."""
+    """train.validate_epoch (train.py:108-134): eval; per batch y_pred = model.predict(X), y = crop_center(y, y_pred),
+    L1 -- one vr_validate_step (forward, crop and the reduction on the device), same accumulation as the reference."""
     model.eval()
     sum_loss = 0
-    with torch.no_grad():
-        for X_batch, y_batch in dataloader:
-            X_batch = X_batch.to(device)
-            y_batch = y_batch.to(device)
-            y_pred = model.predict(X_batch)
-            y_batch = spec_utils.crop_center(y_batch, y_pred)
-            loss = torch.nn.functional.l1_loss(y_pred, y_batch)
-            sum_loss += loss.item() * len(X_batch)
+    for X_batch, y_batch in dataloader:
+        X_batch = X_batch.to(device)
+        y_batch = y_batch.to(device)
+        loss = model.validate_step(X_batch, y_batch)
+        sum_loss += loss * len(X_batch)
     return sum_loss / len(dataloader.dataset)
-
-
-def cpu_baseline_train(sd, B=2):
-    """CPU oracle train step (fwd + L1 + bwd + Adam) timed on this box's host cores (bench.py)."""
-    import os
-    import time
-    from oracle import train_step as ots, weights as ow
-    n = len(os.sched_getaffinity(0))
-    try:
-        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
-        if quota != 'max':
-            n = min(n, max(1, int(round(int(quota) / int(period)))))
-    except (OSError, ValueError):
-        pass
-    torch.set_num_threads(n)
-    sd = ow.clone_state_dict(sd)
-    X, y = ots.synth_batch(B, T=256, n_fft=2048, seed=0)
-    opt = ots.Adam(lr=1e-3)
-    t0 = time.perf_counter()
-    loss, grads = ots.loss_and_grads(sd, X, y)
-    opt.step(sd, grads)
-    dt = time.perf_counter() - t0
-    return {'value': B * 256 / dt, 'unit': 'spectrogram-frames/sec', 'cores': n, 'kind': 'port',
-            'sample': 'one oracle train step (autograd over the restated net + restated Adam) at batch %d x '
-                      '[2,1025,256], %.1f s wall' % (B, dt)}
