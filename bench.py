@@ -1,22 +1,32 @@
 #!/usr/bin/env python
-"""bench.py -- spectrogram-frames/sec of the MI355X-native vocal-remover hot path.
+"""bench.py -- spectrogram-frames/sec of the MI355X-native vocal-remover hot path (BASELINE.json's metric:
+"spectrogram-frames/sec (infer + train-step), CascadedNet n_fft=2048").
 
-A "step" is one pass of the inference hot path over one synthetic song resident in HBM:
-    STFT -> sliding-window CascadedNet.predict_mask over all 256-frame crops -> stitch ->
-    mask apply -> iSTFT x2                                   (inference.py:147-176 of the reference)
-on CascadedNet(n_fft=2048, hop=1024, 32, 128), fp32, seeded random weights (no baseline.pth is
-shipped), 30 s stereo 44.1 kHz synthetic audio -> 1292 frames, 11 crops.
-With N GPUs every rank separates its own song (songs shard with no collective): weak scaling.
+A "step" of the headline `value` is one pass of the inference hot path over one synthetic song resident in HBM
+(configs[1]):  STFT -> sliding-window CascadedNet.predict_mask over all 256-frame crops -> stitch -> mask apply ->
+iSTFT x2  (inference.py:147-176 of the reference) on CascadedNet(n_fft=2048, hop=1024, 32, 128), fp32, seeded random
+weights (no baseline.pth is shipped), 30 s stereo 44.1 kHz synthetic audio -> 1292 frames, 11
+crops.  With N GPUs every rank separates its own song (songs shard with no collective): weak scaling.
 
-`--mode train` times the train.py step (fwd + L1 + bwd + Adam, batch 16 x [2,1025,256]) instead.
+The same JSON line carries the other two single-GPU configurations as sub-objects, each timed over its own K steps
+between barriers after the headline region:
+    "tta"    configs[2]: the same song through Separator.separate_tta (23 crops)
+    "train"  configs[3]: the train.py step (fwd + L1 + bwd [+ RCCL all-reduce of the flat gradient bucket over the N
+             ranks] + Adam), batch 16 x [2,1025,256] per GPU
+plus `roofline` (dominant kernel family = the fp32-MFMA convs: algorithmic FLOPs / HIP-event time per launch, summed
+over the launches of one step; HBM traffic per launch from the committed rocprofv3 PMC passes) and `cpu_baseline`
+(the CPU oracle -- a port of the reference's path, kind "port" -- timed on this box's host cores, N=1 only).
 
-Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel: the
-fp32-MFMA conv family, algorithmic FLOPs / HIP-event time per launch, summed over the launches of
-one step) and `cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded excerpt).
+`python bench.py --gpus N` without a torch.distributed environment launches its own N ranks
+(python -m torch.distributed.run); under the driver's launcher it just reads RANK / WORLD_SIZE.
+`--mode infer|tta|train` times one configuration only (profiling runs).
 """
 import argparse
+import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -72,8 +82,9 @@ def usable_cores():
     return n
 
 
+# ---- cpu_baseline legs: the only place bench.py touches oracle/ (the checker, timed beside the product) -----------
 def cpu_baseline_infer(sd, frames=1292):
-    """CPU oracle (port of the reference's path) on a bounded excerpt of the same song."""
+    """CPU oracle (port of the reference's path) on the same song once."""
     from oracle import separator as osep, stft_np
     cores = usable_cores()
     torch.set_num_threads(cores)
@@ -87,15 +98,45 @@ def cpu_baseline_infer(sd, frames=1292):
     dt = time.perf_counter() - t0
     T = spec.shape[2]
     return {'value': T / dt, 'unit': 'spectrogram-frames/sec', 'cores': cores, 'kind': 'port',
-            'sample': 'the same workload once: %d frames (%.1f s of synthetic audio, %d crops), oracle '
-                      'STFT->separate(batch 4)->iSTFT x2, %.1f s wall' % (T, L / SR, -(-T // 128) + 1, dt)}
+            'sample': 'the same workload once: %d frames (%.1f s of synthetic audio, %d crops), oracle (port of the '
+                      'reference path, torch CPU) STFT->separate(batch 4)->iSTFT x2, %.1f s wall' % (T, L / SR, -(-T // 128) + 1, dt)}
+
+
+def cpu_baseline_train(sd, B=2):
+    """CPU oracle train step (fwd + L1 + bwd + Adam) on a bounded sample: batch 2 of the same crop shape."""
+    from oracle import train_step as ots, weights as ow
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    sd = ow.clone_state_dict(sd)
+    X, y = ots.synth_batch(B, T=CROP, n_fft=N_FFT, seed=0)
+    opt = ots.Adam(lr=1e-3)
+    t0 = time.perf_counter()
+    loss, grads = ots.loss_and_grads(sd, X, y)
+    opt.step(sd, grads)
+    dt = time.perf_counter() - t0
+    return {'value': B * CROP / dt, 'unit': 'spectrogram-frames/sec', 'cores': cores, 'kind': 'port',
+            'sample': 'one oracle train step (port: autograd over the restated net + restated Adam) at batch %d x '
+                      '[2,1025,256] (the GPU runs batch 16), %.1f s wall' % (B, dt)}
 
 
 CONV_FAMILY_INFER = ('conv family on v_mfma_f32_32x32x2_f32: conv_wino_kernel<*> (Winograd F(2x2,3x3), the 3x3 stride-1 '
                      'layers) + conv_dma_kernel<*> (direct implicit GEMM: stride-2, dilated, 1x1, thin layers)')
 CONV_FAMILY_TRAIN = ('conv family on v_mfma_f32_32x32x2_f32: conv_wino_kernel<*> / conv_dma_kernel<*> (forward + data '
                      'gradients over materialised plain tensors; stride-2 data gradient = 4 tap-masked parity convs) + '
-                     'wgrad_ws_kernel<*> (weight gradient, LDS-DMA loader)')
+                     'wgrad_*_kernel<*> (weight gradient, LDS-DMA loader)')
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves (one process per GPU)."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -103,140 +144,190 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--mode', choices=['infer', 'train'], default='infer')
+    ap.add_argument('--mode', choices=['all', 'infer', 'tta', 'train'], default='all')
     ap.add_argument('--seconds', type=float, default=30.0)
-    ap.add_argument('--tta', action='store_true')
+    ap.add_argument('--tta', action='store_true', help='same as --mode tta')
     ap.add_argument('--batchsize', type=int, default=0, help='crops per device batch (0 = all crops of a pass)')
     ap.add_argument('--train-batch', type=int, default=16)
+    ap.add_argument('--wire', choices=['fp32', 'bf16'], default='fp32', help='gradient bucket format on xGMI (N > 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
+    if args.tta:
+        args.mode = 'tta'
     if os.environ.get('VR_BENCH_WATCHDOG'):
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ['VR_BENCH_WATCHDOG']), exit=True)
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        self_launch(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and rank == 0:
+        print('bench.py: --gpus %d but the launcher started %d ranks; measuring %d' % (args.gpus, world, world), file=sys.stderr)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
     if not os.path.exists(__graft_entry__.LIB):
         __graft_entry__.build()
     vr = __graft_entry__.load_package()
+    nat = vr.native
     net, sd = seeded_state(vr)
     net.to(dev)
 
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(step, steps, warmup):
+        """W untimed warm-up steps, then EXACTLY K steps between barriers; MAX over ranks."""
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    def conv_profile(step):
+        """HIP events (on the library's stream) around every MFMA-conv launch of one step, kernels serialised."""
+        nat.check(nat.lib().vr_profile_begin(net._handle.h))
+        step()
+        cms, cfl, cn, cby = ctypes.c_double(), ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
+        nat.check(nat.lib().vr_profile_end(net._handle.h, ctypes.byref(cms), ctypes.byref(cfl), ctypes.byref(cn), ctypes.byref(cby)))
+        return cms.value, cfl.value, cn.value, cby.value
+
+    def roofline(step, kernel, pmc_name):
+        cms, cfl, cn, cby = conv_profile(step)
+        achieved = cfl / (cms * 1e-3) / 1e12 if cms > 0 else 0.0
+        traffic, src = None, None
+        path = os.path.join(ROOT, 'profiles', pmc_name)
+        if os.path.exists(path):        # rocprofv3 PMC passes of this same command (counters cannot be read in-process)
+            traffic = json.load(open(path)).get('bytes_per_launch')
+            src = 'profiles/' + pmc_name
+        return {'bound': 'mfma', 'kernel': kernel, 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
+                'traffic_unit': 'HBM bytes per launch (mean over the conv launches of a step; rocprofv3 FETCH_SIZE x2 '
+                                'gfx950 correction + WRITE_SIZE, %s)' % src,
+                'algorithmic_bytes_per_launch': cby / max(cn, 1),
+                'achieved_note': 'algorithmic FLOPs = 2 x multiply-adds of the direct convolutions / summed launch '
+                                 'durations (HIP events); the Winograd launches execute 2.25x fewer',
+                'launches_per_step': cn, 'kernel_ms_per_step': cms, 'algorithmic_gflop_per_step': cfl / 1e9}
+
     L = int(round(args.seconds * SR))
     T = 1 + L // HOP
-    if args.mode == 'infer':
-        net.eval()
-        sp = vr.inference.Separator(net, dev, batchsize=args.batchsize, cropsize=CROP)
-        wave = torch.from_numpy(synth_wave(args.seconds, rank)).to(dev)
+    pl, pr, roi = vr.dataset.make_padding(T, CROP, 64)
+    crops_plain = (T + pl + pr - 128) // roi
+    crops_tta = crops_plain + (T + pl + pr + roi - 128) // roi
+    wave_host = synth_wave(args.seconds, rank)
+    wave = torch.from_numpy(wave_host).to(dev)
+    sp = vr.inference.Separator(net, dev, batchsize=args.batchsize, cropsize=CROP)
 
-        def step():
-            return sp.separate_wave(wave, tta=args.tta)
-        frames_per_step = T
-        pl, pr, roi = vr.dataset.make_padding(T, CROP, 64)
-        crops = (T + pl + pr - 128) // roi
-        if args.tta:
-            crops += (T + pl + pr + roi - 128) // roi
-        workload = ('configs[1]: 30 s stereo 44.1 kHz synthetic song, STFT -> %d crops of 256 frames in one '
-                    'device batch -> predict_mask -> stitch -> mask apply -> iSTFT x2' % crops) if args.seconds == 30.0 \
-            else '%.0f s synthetic song, %d crops' % (args.seconds, crops)
-        if args.tta:
-            workload += ' (--tta: configs[2])'
-    else:
-        from vocal_remover_amd import train as vtrain       # noqa: E402
-        trainer = vtrain.Trainer(net, lr=1e-3, world_size=world, rank=rank)
+    def run_infer(tta):
+        net.eval()
+        step = lambda: sp.separate_wave(wave, tta=tta)                     # noqa: E731
+        dt = timed(step, args.steps, args.warmup)
+        crops = crops_tta if tta else crops_plain
+        res = {'frames_per_sec': world * T * args.steps / dt, 'ms_per_step': dt / args.steps * 1e3,
+               'computed_frames_per_sec': world * crops * CROP * args.steps / dt, 'crops_per_step_per_gpu': crops,
+               'frames_per_step_per_gpu': T}
+        return res, step
+
+    def run_train():
+        from vocal_remover_amd import train as vtrain
+        trainer = vtrain.Trainer(net, lr=1e-3, world_size=world, rank=rank, backend='rccl' if world > 1 else 'none',
+                                 wire=args.wire if world > 1 else 'fp32')
         g = torch.Generator().manual_seed(rank)
         B = args.train_batch
         X = torch.rand((B, 2, N_FFT // 2 + 1, CROP), generator=g)
         y = (X * torch.rand((B, 2, N_FFT // 2 + 1, CROP), generator=g)).to(dev)
         X = X.to(dev)
+        step = lambda: trainer.step(X, y)                                   # noqa: E731
+        dt = timed(step, args.steps, args.warmup)
+        res = {'frames_per_sec': world * B * CROP * args.steps / dt, 'ms_per_step': dt / args.steps * 1e3,
+               'global_batch': world * B, 'frames_per_step_per_gpu': B * CROP,
+               'workload': 'configs[3]: train.py step, batch %d x [2,1025,256] per GPU, fwd + L1 + bwd%s + Adam; '
+                           'Dropout2d live (library RNG)' % (B, ' + RCCL all-reduce (%s bucket)' % args.wire if world > 1 else ''),
+               'parallelism': 'dp%d (one RCCL all-reduce of the flat 14.74 M-element gradient bucket per step)' % world}
+        return res, step
 
-        def step():
-            return trainer.step(X, y)
-        frames_per_step = B * CROP
-        crops = B
-        workload = 'configs[3]: train.py step, batch %d x [2,1025,256] per GPU, fwd + L1 + bwd + Adam' % B
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
-    # roofline of the dominant kernel family, measured live with HIP events on the library's stream
-    nat = vr.native
-    import ctypes
-    nat.check(nat.lib().vr_profile_begin(net._handle.h))
-    step()
-    cms, cfl, cn, cby = ctypes.c_double(), ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
-    nat.check(nat.lib().vr_profile_end(net._handle.h, ctypes.byref(cms), ctypes.byref(cfl), ctypes.byref(cn),
-                                       ctypes.byref(cby)))
-    achieved = cfl.value / (cms.value * 1e-3) / 1e12 if cms.value > 0 else 0.0
-
-    # HBM traffic of the dominant kernel: rocprofv3 PMC passes of this same command (collected
-    # separately -- counters cannot be read from inside the process), summary committed in profiles/
-    traffic = None
-    pmc_path = os.path.join(ROOT, 'profiles', 'r01_infer_pmc.json')
-    if args.mode == 'infer' and not args.tta and args.seconds == 30.0 and os.path.exists(pmc_path):
-        traffic = json.load(open(pmc_path)).get('bytes_per_launch')
-
+    primary_mode = 'infer' if args.mode == 'all' else args.mode
+    out, extra = None, {}
+    if primary_mode in ('infer', 'tta'):
+        res, step = run_infer(primary_mode == 'tta')
+        workload = ('configs[%d]: 30 s stereo 44.1 kHz synthetic song, STFT -> %d crops of 256 frames in one device batch -> '
+                    'predict_mask -> stitch -> mask apply -> iSTFT x2%s' % (2 if primary_mode == 'tta' else 1, res['crops_per_step_per_gpu'],
+                                                                             ' (--tta)' if primary_mode == 'tta' else '')) \
+            if args.seconds == 30.0 else '%.0f s synthetic song, %d crops' % (args.seconds, res['crops_per_step_per_gpu'])
+        metric = 'spectrogram-frames/sec (inference, CascadedNet n_fft=2048)'
+        parallelism = 'replicas x%d (songs shard, no collective)' % world
+        roof = roofline(step, CONV_FAMILY_INFER, 'r02_infer_pmc.json' if primary_mode == 'infer' else 'r02_tta_pmc.json')
+    else:
+        res, step = run_train()
+        workload, metric, parallelism = res['workload'], 'spectrogram-frames/sec (train-step, CascadedNet n_fft=2048)', res['parallelism']
+        roof = roofline(step, CONV_FAMILY_TRAIN, 'r02_train_pmc.json')
+        net.eval()
     if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
         out = {
-            'metric': 'spectrogram-frames/sec (%s, CascadedNet n_fft=2048)' % ('inference' if args.mode == 'infer' else 'train-step'),
-            'value': world * frames_per_step * args.steps / dt,
-            'unit': 'spectrogram-frames/sec',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+            'metric': metric, 'value': res['frames_per_sec'], 'unit': 'spectrogram-frames/sec',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': res['ms_per_step'],
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic (seeded noise + sines; seeded random weights, no baseline.pth exists)',
             'config': {'workload': workload, 'n_fft': N_FFT, 'hop': HOP, 'cropsize': CROP,
-                       'frames_per_step_per_gpu': frames_per_step, 'crops_per_step_per_gpu': crops,
-                       'computed_frames_per_sec': world * crops * CROP * args.steps / dt,
-                       'parallelism': 'replicas x%d (songs shard, no collective)' % world if args.mode == 'infer'
-                       else 'dp%d (RCCL all-reduce of one flat fp32 gradient bucket)' % world},
-            'roofline': {'bound': 'mfma',
-                         'kernel': CONV_FAMILY_INFER if args.mode == 'infer' else CONV_FAMILY_TRAIN,
-                         'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
-                         'traffic_unit': 'HBM bytes per launch (mean over the conv launches of a step; rocprofv3 '
-                                         'FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/r01_infer_pmc.json)',
-                         'algorithmic_bytes_per_launch': cby.value / max(cn.value, 1),
-                         'achieved_note': 'algorithmic FLOPs = 2 x multiply-adds of the direct convolutions / summed '
-                                          'launch durations (HIP events); the Winograd launches execute 2.25x fewer',
-                         'launches_per_step': cn.value, 'kernel_ms_per_step': cms.value,
-                         'algorithmic_gflop_per_step': cfl.value / 1e9},
+                       'frames_per_step_per_gpu': res['frames_per_step_per_gpu'], 'parallelism': parallelism,
+                       'input_residency': 'inputs resident in HBM when the timed region starts'},
+            'roofline': roof,
         }
-        if world == 1 and not args.no_cpu_baseline and args.mode == 'infer':
-            out['cpu_baseline'] = cpu_baseline_infer(sd)
-        elif world == 1 and not args.no_cpu_baseline:
-            from vocal_remover_amd import train as vtrain
-            out['cpu_baseline'] = vtrain.cpu_baseline_train(sd)
+        if 'computed_frames_per_sec' in res:
+            out['config']['crops_per_step_per_gpu'] = res['crops_per_step_per_gpu']
+            out['config']['computed_frames_per_sec'] = res['computed_frames_per_sec']
+
+    if args.mode == 'all':
+        # PCIe-inclusive rate of the headline workload: host numpy in, host numpy out (2 x 10.6 MB + 2 x 10.6 MB per step)
+        if world == 1:
+            net.eval()
+            dt = timed(lambda: sp.separate_wave(wave_host, tta=False), max(3, args.steps // 2), 1)
+            extra['pcie_inclusive_frames_per_sec'] = T * max(3, args.steps // 2) / dt
+        tta_res, tta_step = run_infer(True)
+        tta_roof = roofline(tta_step, CONV_FAMILY_INFER, 'r02_tta_pmc.json')
+        train_res, train_step_fn = run_train()
+        train_roof = roofline(train_step_fn, CONV_FAMILY_TRAIN, 'r02_train_pmc.json')
+        net.eval()
+        if rank == 0:
+            out['config']['pcie_inclusive_frames_per_sec'] = extra.get('pcie_inclusive_frames_per_sec')
+            out['tta'] = {'metric': 'spectrogram-frames/sec (inference --tta, configs[2])', 'value': tta_res['frames_per_sec'],
+                          'ms_per_step': tta_res['ms_per_step'], 'steps': args.steps, 'warmup': args.warmup,
+                          'crops_per_step_per_gpu': tta_res['crops_per_step_per_gpu'],
+                          'computed_frames_per_sec': tta_res['computed_frames_per_sec'], 'roofline': tta_roof}
+            out['train'] = {'metric': 'spectrogram-frames/sec (train-step, configs[3])', 'value': train_res['frames_per_sec'],
+                            'ms_per_step': train_res['ms_per_step'], 'steps': args.steps, 'warmup': args.warmup,
+                            'global_batch': train_res['global_batch'], 'workload': train_res['workload'],
+                            'parallelism': train_res['parallelism'], 'dtype': 'f32', 'roofline': train_roof}
+
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            if primary_mode in ('infer', 'tta'):
+                out['cpu_baseline'] = cpu_baseline_infer(sd)
+            else:
+                out['cpu_baseline'] = cpu_baseline_train(sd)
+            if args.mode == 'all':
+                out['train']['cpu_baseline'] = cpu_baseline_train(sd)
         print(json.dumps(out))
     if world > 1:
-        import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -1,12 +1,15 @@
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in KB).
-Usage: pmc_summary.py fetch.db write.db [steps_in_pass out.json]  -- the JSON is what bench.py reads for
-`roofline.traffic` (conv family, FETCH_SIZE x2 = the gfx950 correction of MI355X_MICROARCH.md)."""
+Usage: pmc_summary.py fetch.db write.db [steps_in_pass out.json [mode]]  -- the JSON is what bench.py reads for
+`roofline.traffic` (conv family, FETCH_SIZE x2 = the gfx950 correction of MI355X_MICROARCH.md).
+mode = infer (default) | tta | train: names the bench.py command the passes ran."""
 import json
 import re
 import sqlite3
 import sys
 
-FAMILY = 'conv family (conv_wino + conv_dma + conv_ws + conv_mfma)'
+FAMILY = 'conv family (conv_wino + conv_dma + conv_ws + conv_mfma + wgrad)'
+KEYS = ('conv_mfma_kernel', 'conv_ws_kernel', 'conv_dma_kernel', 'conv_wino_kernel', 'wgrad_ws_kernel', 'wgrad_mfma_kernel',
+        'wgrad_dma_kernel')
 
 
 def load(path, counter):
@@ -14,7 +17,7 @@ def load(path, counter):
     out = {}
     for name, val in db.execute("select name, counter_value from pmc_events where counter_name=? order by start", (counter,)):
         name = re.sub(r'^void ', '', name)
-        conv = any(k in name for k in ('conv_mfma_kernel', 'conv_ws_kernel', 'conv_dma_kernel', 'conv_wino_kernel'))
+        conv = any(k in name for k in KEYS)
         name = FAMILY if conv else re.sub(r'\(.*$', '', name)[:60]
         n, s = out.get(name, (0, 0.0))
         out[name] = (n + 1, s + val)
@@ -28,15 +31,16 @@ print('|---|---|---|---|')
 for k in sorted(f, key=lambda k: -f[k][1]):
     print('| %s | %d | %.1f | %.1f |' % (k, f[k][0], f[k][1] / 1024, w.get(k, (0, 0))[1] / 1024))
 if len(sys.argv) > 4:
+    mode = sys.argv[5] if len(sys.argv) > 5 else 'infer'
     n, fk = f[FAMILY]
     wk = w[FAMILY][1]
     json.dump({
         'command': 'VR_NO_SIDE_STREAM=1 VR_NO_SPLIT_BATCH=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python bench.py '
-                   '--steps 1 --warmup 0 --no-cpu-baseline (two separate passes, single stream so kernels do not overlap)',
+                   '--mode %s --steps 1 --warmup 0 --no-cpu-baseline (two separate passes, single stream so kernels do not overlap)' % mode,
         'kernel': FAMILY, 'launches_in_pass': n, 'steps_in_pass': int(sys.argv[3]),
         'fetch_size_kb_raw': fk, 'write_size_kb_raw': wk, 'fetch_correction': 2.0,
-        'note': 'gfx950 FETCH_SIZE reads 1/2 of streamed bytes (MI355X_MICROARCH.md, HBM section); calibrated in the first '
-                'round-1 pass on kernels with known traffic (thin_conv_kernel<2,true>: 369.1 MB algorithmic vs 176.0 MB '
+        'note': 'gfx950 FETCH_SIZE reads 1/2 of streamed bytes (MI355X_MICROARCH.md, HBM section); calibrated in round 1 '
+                'on kernels with known traffic (thin_conv_kernel<2,true>: 369.1 MB algorithmic vs 176.0 MB '
                 'reported = 0.477; WRITE_SIZE matches: 11.5 MB vs 11.0 MB).',
         'bytes_per_launch': (2.0 * fk + wk) * 1024.0 / n,
     }, open(sys.argv[4], 'w'), indent=1)
