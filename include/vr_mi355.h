@@ -116,8 +116,10 @@ int vr_augment_batch(vr_handle h, const float* X, const float* y, const float* X
                      int out_on_device);
 
 /* torch.optim.Adam(lr, betas=(b1,b2), eps, weight_decay=0).step()   train.py:215-218,95
- * grad_scale multiplies every gradient first (1/world_size after a SUM all-reduce).                */
-int vr_adam_step(vr_handle h, float lr, float b1, float b2, float eps, float grad_scale);
+ * grad_scale multiplies every gradient first (1/world_size after a SUM all-reduce).  Hyper-parameters are doubles
+ * like torch's python floats: 1 - beta, the bias corrections and lr / bias_correction1 are formed in double and only
+ * then rounded to the fp32 the parameters live in (1 - 0.999f differs from 0.001f by 1.3e-5 relative).          */
+int vr_adam_step(vr_handle h, double lr, double b1, double b2, double eps, double grad_scale);
 int vr_zero_grad(vr_handle h);                                          /* model.zero_grad(), train.py:96 */
 int vr_get_grad(vr_handle h, const char* key, float* host, int64_t capacity_bytes);   /* param.grad, torch layout */
 /* nn.Dropout2d(0.1) on the five ASPP outputs (lib/layers.py:90), live in train mode.  mode 1 (the DEFAULT, as in

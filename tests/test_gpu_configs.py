@@ -175,7 +175,12 @@ def test_full_net_train_step(vr, full):
     sdm = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     want_mask = cascaded_net.forward(X.double(), sdm, n_fft=N_FFT, training=True, update_running=False,
                                      dropout={k: v.double() for k, v in masks.items()})
-    assert float((mask.cpu().double() - want_mask).abs().max()) < 1e-4
+    # train-mode BatchNorm over a batch of 2 amplifies fp32 rounding: the bar is the fp32 CPU oracle's own deviation
+    mask32 = cascaded_net.forward(X, weights.clone_state_dict(sd), n_fft=N_FFT, training=True, update_running=False, dropout=masks)
+    e32 = float((mask32.double() - want_mask).abs().max())
+    e_gpu = float((mask.cpu().double() - want_mask).abs().max())
+    print('train-mode mask max-abs vs fp64 oracle: gpu %.3e, cpu fp32 oracle %.3e' % (e_gpu, e32))
+    assert e_gpu < max(1e-4, 3 * e32)
 
 
 # ---- small net: fixtures generated from the reference itself ---------------------------------------------------

@@ -182,7 +182,7 @@ int vr_augment_batch(vr_handle h, const float* X, const float* y, const float* X
     });
 }
 
-int vr_adam_step(vr_handle h, float lr, float b1, float b2, float eps, float grad_scale) {
+int vr_adam_step(vr_handle h, double lr, double b1, double b2, double eps, double grad_scale) {
     NEED(h);
     return guard([&] { h->m.adam_step_api(lr, b1, b2, eps, grad_scale); });
 }

@@ -6,6 +6,8 @@
 // BatchNorm backward turns G_T (in place) into dz, the gradient at the RAW conv output:
 //     dy = G * post * act'(y),  y = z*scale + shift
 //     dz = scale * (dy - mean(dy) - xhat * mean(dy*xhat))  =  kA*dy + kB*z + kC      (per channel)
+#include <cmath>
+
 #include "kernels.h"
 
 namespace vr {
@@ -512,22 +514,24 @@ void launch_flip_transpose(const FlipDesc* d_descs, int n, hipStream_t st) {
 // torch.optim.Adam defaults (train.py:215-218) over the flat parameter arena, one launch.
 // ---------------------------------------------------------------------------------------------------
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            long long n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale) {
+                            long long n, float b1, float b2, float omb1, float omb2, float step_size, float bc2_sqrt, float eps,
+                            float gscale) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float gi = g[i] * gscale;
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float mi = b1 * m[i] + omb1 * gi;              // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = b2 * v[i] + omb2 * gi * gi;         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
     m[i] = mi; v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] -= (lr / bc1) * (mi / denom);
+    p[i] -= step_size * (mi / denom);                    // param.addcdiv_(exp_avg, denom, value=-lr / bias_correction1)
 }
-void launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
-                 long long step, float gscale, hipStream_t st) {
-    const float bc1 = 1.f - powf(b1, (float)step);
-    const float bc2s = sqrtf(1.f - powf(b2, (float)step));
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, bc1,
-                       bc2s, gscale);
+void launch_adam(float* p, const float* g, float* m, float* v, long long n, double lr, double b1, double b2, double eps,
+                 long long step, double gscale, hipStream_t st) {
+    // scalars in double, as torch's python floats are (torch/optim/adam.py _single_tensor_adam)
+    const double bc1 = 1.0 - std::pow(b1, (double)step);
+    const double bc2s = std::sqrt(1.0 - std::pow(b2, (double)step));
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n, (float)b1, (float)b2,
+                       (float)(1.0 - b1), (float)(1.0 - b2), (float)(lr / bc1), (float)bc2s, (float)eps, (float)gscale);
     VR_HIP(hipGetLastError());
 }
 

@@ -1,6 +1,8 @@
 // Test hooks (tests/ only): single kernels of the training path behind vr_debug_kernel, host pointers in and out,
 // so that every backward kernel has an isolated parity test against torch autograd (tests/test_gpu_kernels.py).
+#include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "model.h"
@@ -154,8 +156,15 @@ void Model::debug_kernel(const std::string& name, const int64_t* dims, int ndims
     } else if (name == "adam") {
         need(1, 6, 4, 3);
         const size_t n = (size_t)dims[0];
+        // the float parameters arrive as fp32; snap them back to the decimal doubles the optimizer was built with
+        double dp[6];
+        for (int i = 0; i < 6; ++i) {
+            char buf[48];
+            std::snprintf(buf, sizeof buf, "%.7g", (double)fp[i]);
+            dp[i] = std::strtod(buf, nullptr);
+        }
         DevBuf p(in[0], n), g(in[1], n), m(in[2], n), v(in[3], n);
-        launch_adam(p.p, g.p, m.p, v.p, (long long)n, fp[0], fp[1], fp[2], fp[3], (long long)fp[5], fp[4], st);
+        launch_adam(p.p, g.p, m.p, v.p, (long long)n, dp[0], dp[1], dp[2], dp[3], (long long)dp[5], dp[4], st);
         VR_HIP(hipStreamSynchronize(st));
         p.download(out[0]); m.download(out[1]); v.download(out[2]);
     } else {

@@ -101,8 +101,8 @@ void launch_head_loss(const Tensor& x, const float* w, const float* X, const flo
                       float* dlogit, float* mask_out, float* loss_part, float* loss_out, float loss_scale, hipStream_t st);
 struct FlipDesc { const float* w; float* wt; int Cin, Cout, KK, CinPad, CoutPad; };
 void launch_flip_transpose(const FlipDesc* d_descs, int n, hipStream_t st);
-void launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
-                 long long step, float gscale, hipStream_t st);
+void launch_adam(float* p, const float* g, float* m, float* v, long long n, double lr, double b1, double b2, double eps,
+                 long long step, double gscale, hipStream_t st);
 void launch_channel_sum(const float* d, int N, int C, int W, float* out, int accumulate, hipStream_t st);
 void launch_f32_to_bf16(const float* x, unsigned short* y, long long n, hipStream_t st);
 void launch_bf16_to_f32(const unsigned short* x, float* y, long long n, hipStream_t st);

@@ -253,7 +253,7 @@ public:
     // train.py:77-96: forward (train mode) + L1 loss + backward; gradients accumulate in the arena.
     void train_fwd_bwd_api(const float* X, const float* Y, bool on_dev, int B, int T, int accumulation_steps,
                            float* loss_out, float* mask_out, bool mask_on_dev);
-    void adam_step_api(float lr, float b1, float b2, float eps, float grad_scale);
+    void adam_step_api(double lr, double b1, double b2, double eps, double grad_scale);
     void zero_grad_api();
     void get_grad(const std::string& key, float* host, int64_t cap_bytes);
     void set_dropout(int mode, unsigned long long seed, const float* masks, int B);

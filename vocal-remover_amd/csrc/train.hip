@@ -504,7 +504,7 @@ void Model::reset_adam_state() {
     }
 }
 
-void Model::adam_step_api(float lr, float b1, float b2, float eps, float grad_scale) {
+void Model::adam_step_api(double lr, double b1, double b2, double eps, double grad_scale) {
     DeviceGuard dev_guard(device);
     ensure_train_state();
     adam_step += 1;

@@ -32,7 +32,7 @@ _SIGNATURES = {
                                         ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, ctypes.c_int]),
     'vr_train_step': (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, ctypes.POINTER(ctypes.c_float), c_f32p, ctypes.c_int]),
-    'vr_adam_step': (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_float] * 5),
+    'vr_adam_step': (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_double] * 5),
     'vr_zero_grad': (ctypes.c_int, [ctypes.c_void_p]),
     'vr_get_grad': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_f32p, ctypes.c_int64]),
     'vr_set_dropout': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, c_f32p, ctypes.c_int]),
