@@ -44,6 +44,12 @@ BWD_CASES = [
     (2, 40, 16, 32, 8, 1, 1, 1, 1, 0, 1, 0.0),       # 1x1
     (1, 320, 16, 16, 128, 1, 1, 1, 1, 0, 1, 0.0),
     (2, 12, 8, 16, 32, 3, 1, 1, 1, 1, 1, 0.0),       # through the fused bilinear x2 upsample
+    # plain inputs (no pending affine / activation): the weight gradient takes the Winograd F(3x3,2x2) kernel
+    (1, 40, 24, 64, 64, 3, 1, 1, 1, 0, 0, 1.0),      # 32 input channels x 64 couts per block
+    (2, 97, 12, 48, 32, 3, 1, 1, 1, 0, 0, 1.0),      # 64 x 32 blocks, Cin = 97 (one live channel in the last block)
+    (1, 70, 10, 16, 96, 3, 1, 1, 1, 0, 0, 1.0),      # CoutPad 96, H not a multiple of the 4-row chunk, 16 columns
+    (2, 33, 9, 20, 128, 3, 1, 1, 1, 0, 0, 1.0),      # odd H, W = 20 (partial 16-column chunk)
+    (1, 16, 8, 32, 16, 3, 1, 1, 1, 0, 0, 1.0),       # 32 x 32 blocks, couts padded 16 -> 32
 ]
 
 

@@ -165,6 +165,7 @@ void Model::bwd_conv(TapeRec& r) {
         if (r.batch_as_h) { w.zN = 0; w.zC = out.sC; w.zH = out.sN; }
         else { w.zN = out.sN; w.zC = out.sC; w.zH = out.sH; }
         w.Cout = L.Cout; w.CoutPad = L.CoutPad;
+        w.allow_wino = train_wino ? 1 : 0;
         w.part = ws.allocf(wgrad_scratch_floats(w, shp));
         if (!dry) {
             // The weight gradient is off the critical path (dz -> data gradient -> previous layer): it runs on the

@@ -147,6 +147,7 @@ struct WgradArgs {
     long long part_stride;
     int P, tiles_w, tiles_h, npt, nchunks, nct;
     int dma;                   // 1: every source is a plain tensor -> the loader waves use LDS-DMA (no arithmetic)
+    int allow_wino;            // 1: 3x3 stride-1 layers with plain inputs may take the Winograd F(3x3,2x2) kernel (wgrad_wino.hip)
 };
 double launch_wgrad(const WgradArgs& a, const ConvShape& s, float* grad_out, int accumulate, hipStream_t st);
 size_t wgrad_scratch_floats(const WgradArgs& a, const ConvShape& s);

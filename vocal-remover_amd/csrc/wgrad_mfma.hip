@@ -434,6 +434,10 @@ static WgTile wg_pick(const WgradArgs& a, const ConvShape& s) {
     return t;
 }
 
+bool wgrad_wino_pick(const WgradArgs& a, const ConvShape& s, int* CB_out, int* MT_out);     // wgrad_wino.hip
+void wgrad_wino_plan(WgradArgs& a, int CB, int MT);
+void wgrad_wino_launch(const WgradArgs& a, int CB, int MT, hipStream_t st);
+
 void wgrad_plan(WgradArgs& a, const ConvShape& s) {
     const WgTile t = wg_pick(a, s);
     a.tiles_w = (a.in.Wout + t.TW - 1) / t.TW;
@@ -486,11 +490,27 @@ static void wg_launch_ws(const WgradArgs& a, int MB, hipStream_t st) {
     else wg_launch_ws_inst<KS, S, TH, TW, 1>(a, st);
 }
 
+static void wgrad_reduce(const WgradArgs& a, float* grad_out, int accumulate, hipStream_t st) {
+    const long long n = a.part_stride;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, a.part, a.part_stride,
+                       a.P, grad_out, n, accumulate);
+    VR_HIP(hipGetLastError());
+}
+
 double launch_wgrad(const WgradArgs& a_in, const ConvShape& s, float* grad_out, int accumulate, hipStream_t st) {
     WgradArgs a = a_in;
+    VR_CHECK(a.part != nullptr, -2, "wgrad needs a scratch slab");
+    {
+        int CB = 0, MT = 0;
+        if (wgrad_wino_pick(a, s, &CB, &MT)) {             // Winograd F(3x3,2x2): 2.25x fewer MFMAs
+            wgrad_wino_plan(a, CB, MT);
+            wgrad_wino_launch(a, CB, MT, st);
+            wgrad_reduce(a, grad_out, accumulate, st);
+            return 2.0 * a.in.N * (double)a.in.Hout * a.in.Wout * (double)a.Cout * a.in.Cin * 9;
+        }
+    }
     wgrad_plan(a, s);
     const WgTile t = wg_pick(a, s);
-    VR_CHECK(a.part != nullptr, -2, "wgrad needs a scratch slab");
     {
         static const bool dma_on = !getenv("VR_NO_WGRAD_DMA");
         bool plain = dma_on;
@@ -526,17 +546,26 @@ double launch_wgrad(const WgradArgs& a_in, const ConvShape& s, float* grad_out, 
     } else {
         throw Error(-2, "unsupported wgrad shape");
     }
-    const long long n = a.part_stride;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, a.part, a.part_stride,
-                       a.P, grad_out, n, accumulate);
-    VR_HIP(hipGetLastError());
+    wgrad_reduce(a, grad_out, accumulate, st);
     return 2.0 * a.in.N * (double)a.in.Hout * a.in.Wout * (double)a.Cout * a.in.Cin * s.KS * s.KS;
 }
 
+// Scratch for the P partial slabs.  The kernel choice is re-made at launch time from the real pointers (alignment),
+// so the slab is sized for whichever of the two plans needs more.
 size_t wgrad_scratch_floats(const WgradArgs& a_in, const ConvShape& s) {
     WgradArgs a = a_in;
     wgrad_plan(a, s);
-    return (size_t)a.P * (size_t)a.part_stride;
+    size_t need = (size_t)a.P * (size_t)a.part_stride;
+    if (s.KS == 3 && s.stride == 1 && s.dil_h == 1 && s.dil_w == 1 && a_in.allow_wino) {
+        for (int alt = 0; alt < 3; ++alt) {
+            WgradArgs b = a_in;
+            if (b.CoutPad % (alt == 0 ? 64 : 32)) continue;
+            wgrad_wino_plan(b, alt == 1 ? 64 : 32, alt == 0 ? 64 : 32);
+            const size_t n = (size_t)b.P * (size_t)b.part_stride;
+            if (n > need) need = n;
+        }
+    }
+    return need;
 }
 
 }  // namespace vr

@@ -1,0 +1,334 @@
+// Winograd F(3x3, 2x2) weight gradient of the 3x3 stride-1 convolutions (backward of lib/layers.py:12-20 under
+// train.py:92; ~70 % of the weight-gradient multiply-adds of the net):
+//
+//   dW[co][ci] (3x3) = sum over 2x2 output tiles of   A^T [ (G dz G^T) (.) (B^T x B) ] A
+//
+// dz: the 2x2 tile of the gradient at the conv's raw output, x: the 4x4 input patch around it.  16 multiplies per
+// tile instead of the 36 of the direct form, so the MFMA work drops 2.25x -- the direct kernel (wgrad_mfma.hip)
+// already sits on the fp32 matrix pipe.  The 16 element-wise products are 16 independent GEMMs with the reduction
+// over TILES,   M_f[co][ci] += U_f[co][tile] * V_f[tile][ci],   f = 0..15,
+// on v_mfma_f32_32x32x2_f32 (rows = couts, columns = input channels, k = 2 tiles per instruction).
+//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   (the forward kernel's input transform, conv_wino.hip)
+//   G   = [1 0; 1/2 1/2; 1/2 -1/2; 0 1]              A^T = [1 1 1 0; 0 1 -1 0; 0 1 1 -1]
+//
+// Workgroup = 512 threads / 8 waves, one per CU; block = (CB input channels, MT couts, one of P contiguous ranges of
+// 4x16-pixel chunks = 16 tiles).  Per chunk:
+//   * raw input rows (6 x 24 floats per channel) and raw dz rows (4 x 16 per cout) arrive by LDS-DMA; wave w fetches
+//     input channels w, w+8, ... and couts 4j..4j+3 for j = w, w+8, ...;
+//   * the same wave transforms what it fetched (lane = (tile, one of 4 channels)): no cross-wave dependency between
+//     the DMA and the transform;
+//   * wave w multiplies frequencies 2w and 2w+1; accumulators stay in registers over the whole pixel range;
+//   * at the end the 16 frequencies of a (cout, cin) pair meet in LDS, A^T M A, and the 9 taps go to the block's
+//     partial slab [ci][tap][co]; wgrad_reduce_kernel (wgrad_mfma.hip) sums the P slabs deterministically.
+// fp32 throughout; the transforms only add and halve.
+#include <cstdlib>
+
+#include "conv_stage.h"
+#include "lds_dma.h"
+
+namespace vr {
+
+template <int CB, int MT>
+struct WwCfg {
+    static constexpr int TH = 4, TW = 16, KT = 16;                     // chunk: 4 x 16 output pixels = 2 x 8 Winograd tiles
+    static constexpr int XR = TH + 2, XS0 = 3, TWq = 24, CSX = XR * TWq;   // raw input rows start 4 columns left of the chunk
+    static constexpr int CSZ = TH * TW;                                // raw dz floats per cout
+    static constexpr int KP = KT + 1;                                  // odd k pitch: 32 channels -> 32 banks
+    static constexpr int XRAW = CB * CSX, ZRAW = MT * CSZ;
+    static constexpr int VS = 16 * CB * KP, US = 16 * MT * KP;
+    static constexpr int LDS_FLOATS = XRAW + ZRAW + VS + US;
+    static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+    static constexpr int WM = MT / 32, WN = CB / 32;
+    static constexpr int MP = 33;                                      // epilogue exchange pitch
+    static_assert(CSX == 36 * 4 && CSZ == 16 * 4, "piece counts below");
+    static_assert(16 * 32 * MP <= LDS_FLOATS && LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+template <int CB, int MT>
+__global__ __launch_bounds__(512) void wgrad_wino_kernel(const WgradArgs a) {
+    using Cfg = WwCfg<CB, MT>;
+    constexpr int TH = Cfg::TH, TW = Cfg::TW, TWq = Cfg::TWq, CSX = Cfg::CSX, CSZ = Cfg::CSZ, KP = Cfg::KP, XS0 = Cfg::XS0,
+                  WM = Cfg::WM, WN = Cfg::WN, MP = Cfg::MP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xraw = smem;
+    float* Zraw = smem + Cfg::XRAW;
+    float* Vs = Zraw + Cfg::ZRAW;                      // [16][CB][KP]
+    float* Us = Vs + Cfg::VS;                          // [16][MT][KP]
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int rr = id >> 3;
+    const int inner = a.nchunks * a.nct;
+    const int p = (rr / inner) * 8 + xcd;
+    if (p >= a.P) return;
+    const int ib = rr % inner;
+    const int ct = ib % a.nct, cb = ib / a.nct;
+    const int co0 = ct * MT, c0 = cb * CB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // 0..7
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const int tiles_per_img = a.tiles_h * a.tiles_w;
+    const int t_begin = (int)((long long)p * a.npt / a.P), t_end = (int)((long long)(p + 1) * a.npt / a.P);
+
+    // ---- DMA of one chunk: this wave's input channels and couts ---------------------------------------------------
+    const int xq_row = lane / 6, xq_c4 = lane % 6;                     // lanes 0..35: 16-B piece (row, column quad)
+    const int zq_cs = lane >> 4, zq_row = (lane >> 2) & 3, zq_c4 = lane & 3;
+    auto issue_chunk = [&](int pt) {
+        const int n = pt / tiles_per_img;
+        const int trem = pt - n * tiles_per_img;
+        const int h0 = (trem / a.tiles_w) * TH, w0 = (trem % a.tiles_w) * TW;
+        {
+            const int hi = h0 - 1 + xq_row, wi = w0 - 1 - XS0 + 4 * xq_c4;
+            const bool ok = lane < 36 && hi >= 0 && hi < a.in.Hin && wi >= 0 && wi + 3 < a.in.Win;
+#pragma unroll
+            for (int i = 0; i < CB / 8; ++i) {
+                const int cl = wave + 8 * i;
+                const int ci = c0 + cl;
+                const bool live = ci < a.in.Cin;
+                const int cj = live ? ci : 0;
+                const int si = (cj >= a.in.c1) + (cj >= a.in.c2);
+                const int clc = cj - (si == 0 ? 0 : (si == 1 ? a.in.c1 : a.in.c2));
+                const float* sp = VR_SEL_F(a.in, si, p);
+                const long long sN = VR_SEL_F(a.in, si, sN), sC = VR_SEL_F(a.in, si, sC);
+                const unsigned sH4 = (unsigned)VR_SEL_F(a.in, si, sH) * 4u;
+                const i32x4 xr = make_rsrc(sp + (long long)n * sN + (long long)clc * sC, live ? 0x7FFFFFF0u : 0u);
+                const unsigned vo = ok ? (unsigned)hi * sH4 + (unsigned)(wi * 4) : 0x80000000u;
+                if (lane < 36) dma16(lds0 + (unsigned)(cl * CSX * 4), vo, xr);
+            }
+        }
+        {
+            const int h = h0 + zq_row, w = w0 + 4 * zq_c4;
+            const bool okp = h < a.in.Hout && w + 3 < a.in.Wout;
+            const i32x4 zr = make_rsrc(a.dz + (long long)n * a.zN, 0x7FFFFFF0u);
+#pragma unroll
+            for (int i = 0; i < MT / 32; ++i) {
+                const int j = wave + 8 * i;                            // couts 4j .. 4j+3 of the block
+                const int cg = co0 + 4 * j + zq_cs;
+                const unsigned vo = (okp && cg < a.Cout)
+                                        ? (unsigned)(((long long)cg * a.zC + (long long)h * a.zH + w) * 4)
+                                        : 0x80000000u;
+                dma16(lds0 + (unsigned)((Cfg::XRAW + 4 * j * CSZ) * 4), vo, zr);
+            }
+        }
+    };
+
+    // ---- transforms of what this wave fetched: lane = (tile k, sub-channel) ---------------------------------------
+    const int tk = lane & 15, tsub = lane >> 4;
+    const int ti = tk >> 3, tj = tk & 7;
+    auto transform = [&]() {
+#pragma unroll
+        for (int i = 0; i < CB / 32; ++i) {                            // B^T x B of 4 input channels
+            const int cl = wave + 8 * (4 * i + tsub);
+            const float* xp = Xraw + cl * CSX + (2 * ti) * TWq + 2 * tj + XS0;
+            float* V = Vs + cl * KP + tk;                              // + f * CB * KP
+            float t[4][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float d0 = xp[c], d1 = xp[TWq + c], d2 = xp[2 * TWq + c], d3 = xp[3 * TWq + c];
+                t[0][c] = d0 - d2;
+                t[1][c] = d1 + d2;
+                t[2][c] = d2 - d1;
+                t[3][c] = d1 - d3;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                V[(r * 4 + 0) * CB * KP] = t[r][0] - t[r][2];
+                V[(r * 4 + 1) * CB * KP] = t[r][1] + t[r][2];
+                V[(r * 4 + 2) * CB * KP] = t[r][2] - t[r][1];
+                V[(r * 4 + 3) * CB * KP] = t[r][1] - t[r][3];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MT / 32; ++i) {                            // G dz G^T of 4 couts
+            const int col = 4 * (wave + 8 * i) + tsub;
+            const float* zp = Zraw + col * CSZ + (2 * ti) * TW + 2 * tj;
+            float* U = Us + col * KP + tk;                             // + f * MT * KP
+            const float g00 = zp[0], g01 = zp[1], g10 = zp[TW], g11 = zp[TW + 1];
+            float t[4][2];
+            t[0][0] = g00;                 t[0][1] = g01;
+            t[1][0] = 0.5f * (g00 + g10);  t[1][1] = 0.5f * (g01 + g11);
+            t[2][0] = 0.5f * (g00 - g10);  t[2][1] = 0.5f * (g01 - g11);
+            t[3][0] = g10;                 t[3][1] = g11;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                U[(r * 4 + 0) * MT * KP] = t[r][0];
+                U[(r * 4 + 1) * MT * KP] = 0.5f * (t[r][0] + t[r][1]);
+                U[(r * 4 + 2) * MT * KP] = 0.5f * (t[r][0] - t[r][1]);
+                U[(r * 4 + 3) * MT * KP] = t[r][1];
+            }
+        }
+    };
+
+    const int khalf = lane >> 5, l31 = lane & 31;
+    f32x16 acc[2][WM][WN];
+#pragma unroll
+    for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[fi][mi][ni][r] = 0.f;
+
+    if (t_begin < t_end) {
+        issue_chunk(t_begin);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        transform();
+        lds_barrier();
+    }
+    const float* Ua = Us + (2 * wave) * MT * KP + l31 * KP + khalf;   // + fi*MT*KP + mi*32*KP + 2*s
+    const float* Vb = Vs + (2 * wave) * CB * KP + l31 * KP + khalf;   // + fi*CB*KP + ni*32*KP + 2*s
+    for (int pt = t_begin; pt < t_end; ++pt) {
+        if (pt + 1 < t_end) issue_chunk(pt + 1);       // the raw buffers were last read by this wave's own transform
+        if (!(a.in.dbg & 2)) {
+            // 16 k-steps (2 frequencies x 8 tile pairs), operands of step s+1 read before the MFMAs of step s
+            float av[WM], bv[WN];
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi) av[mi] = Ua[mi * 32 * KP];
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni) bv[ni] = Vb[ni * 32 * KP];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                float avn[WM], bvn[WN];
+                if (s + 1 < 16) {
+                    const int fi = (s + 1) >> 3, kk = (s + 1) & 7;
+#pragma unroll
+                    for (int mi = 0; mi < WM; ++mi) avn[mi] = Ua[fi * MT * KP + mi * 32 * KP + 2 * kk];
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni) bvn[ni] = Vb[fi * CB * KP + ni * 32 * KP + 2 * kk];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni)
+                        acc[s >> 3][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[s >> 3][mi][ni], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + 1 < 16) {
+#pragma unroll
+                    for (int mi = 0; mi < WM; ++mi) av[mi] = avn[mi];
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni) bv[ni] = bvn[ni];
+                }
+            }
+        }
+        if (pt + 1 < t_end) {
+            lds_barrier();                                                 // every wave is done reading U, V of this chunk
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's rows of the next chunk have landed
+            if (!(a.in.dbg & 1)) transform();
+            lds_barrier();
+        }
+    }
+
+    // ---------------- epilogue: gather the 16 frequencies per (cout, cin) through LDS, A^T M A -> 9 taps ---------------
+    float* Mx = smem;                                                  // [16][32 couts][MP]
+    float* pp = a.part + (long long)p * a.part_stride;
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) {
+            lds_barrier();                                             // main loop / previous pass has been read
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * khalf;          // cout within the 32-block
+                    Mx[((2 * wave + fi) * 32 + row) * MP + l31] = acc[fi][mi][ni][r];
+                }
+            lds_barrier();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = tid + 512 * j;
+                const int col = q & 31, cil = q >> 5;                  // lanes along couts: contiguous in the slab
+                float m[16];
+#pragma unroll
+                for (int f = 0; f < 16; ++f) m[f] = Mx[(f * 32 + col) * MP + cil];
+                float s0[4], s1[4], s2[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    s0[c] = m[c] + m[4 + c] + m[8 + c];
+                    s1[c] = m[4 + c] - m[8 + c];
+                    s2[c] = m[4 + c] + m[8 + c] - m[12 + c];
+                }
+                float y[9];
+                y[0] = s0[0] + s0[1] + s0[2]; y[1] = s0[1] - s0[2]; y[2] = s0[1] + s0[2] - s0[3];
+                y[3] = s1[0] + s1[1] + s1[2]; y[4] = s1[1] - s1[2]; y[5] = s1[1] + s1[2] - s1[3];
+                y[6] = s2[0] + s2[1] + s2[2]; y[7] = s2[1] - s2[2]; y[8] = s2[1] + s2[2] - s2[3];
+                const int ci = c0 + ni * 32 + cil;
+                const int co = co0 + mi * 32 + col;
+                if (ci < a.in.Cin && co < a.CoutPad) {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) pp[((long long)ci * 9 + t) * a.CoutPad + co] = y[t];
+                }
+            }
+        }
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------------
+struct WwPick { int CB, MT; };
+
+static bool ww_enabled() {
+    static const bool on = [] { const char* e = getenv("VR_WGRAD_WINO"); return !e || atoi(e) != 0; }();
+    return on;
+}
+
+// True when the launch can take the Winograd weight-gradient kernel: 3x3 stride-1 undilated conv, every source a plain
+// tensor with 16-byte aligned rows (the training executor materialises them), 16-byte aligned dz rows.
+bool wgrad_wino_pick(const WgradArgs& a, const ConvShape& s, int* CB_out, int* MT_out) {
+    if (!ww_enabled() || !a.allow_wino) return false;
+    if (!(s.KS == 3 && s.stride == 1 && s.dil_h == 1 && s.dil_w == 1)) return false;
+    if (a.in.pad_h != 1 || a.in.pad_w != 1 || a.in.Hout != a.in.Hin || a.in.Wout != a.in.Win) return false;
+    if ((a.in.Win & 3) || a.in.Win < 16 || a.in.Hin < 2) return false;
+    for (int i = 0; i < a.in.nsrc; ++i) {
+        const ConvSrc& c = a.in.src[i];
+        if (c.aff0 || c.aff1 || c.post || c.up || c.zins || c.slope != 1.f || c.W != a.in.Win) return false;
+        if ((c.sH & 3) || (c.sC & 3) || (c.sN & 3) || (reinterpret_cast<uintptr_t>(c.p) & 15)) return false;
+        if ((long long)c.H * (c.sH > 0 ? c.sH : 1) * 4 >= 0x7FFFFFF0LL) return false;
+    }
+    if ((a.zH & 3) || (a.zC & 3) || (a.zN & 3) || (reinterpret_cast<uintptr_t>(a.dz) & 15)) return false;
+    if ((long long)a.Cout * a.zC * 4 >= 0x7FFFFFF0LL) return false;
+    const bool m64 = a.CoutPad % 64 == 0;
+    *MT_out = m64 ? 64 : 32;
+    *CB_out = (!m64 && a.in.Cin > 32) ? 64 : 32;
+    return true;
+}
+
+void wgrad_wino_plan(WgradArgs& a, int CB, int MT) {
+    a.tiles_w = (a.in.Wout + 15) / 16;
+    a.tiles_h = (a.in.Hout + 3) / 4;
+    a.npt = a.in.N * a.tiles_h * a.tiles_w;
+    a.nchunks = (a.in.Cin + CB - 1) / CB;
+    a.nct = a.CoutPad / MT;
+    a.part_stride = (long long)a.in.Cin * 9 * a.CoutPad;
+    long long P = 512 / ((long long)a.nchunks * a.nct);        // one workgroup per CU: two rounds of 256
+    if (P < 1) P = 1;
+    if (P > a.npt) P = a.npt;
+    const long long cap = (64LL << 20) / a.part_stride;       // scratch <= 256 MB
+    if (P > cap) P = cap < 1 ? 1 : cap;
+    a.P = (int)P;
+}
+
+template <int CB, int MT>
+static void ww_launch(const WgradArgs& a, hipStream_t st) {
+    using Cfg = WwCfg<CB, MT>;
+    auto kern = wgrad_wino_kernel<CB, MT>;
+    static std::atomic<unsigned long long> attr_done{0};          // per device (bit = device index)
+    ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
+    const int grid = ((a.P + 7) / 8) * 8 * a.nchunks * a.nct;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), Cfg::LDS_BYTES, st, a);
+    VR_HIP(hipGetLastError());
+}
+
+void wgrad_wino_launch(const WgradArgs& a_in, int CB, int MT, hipStream_t st) {
+    WgradArgs a = a_in;
+    static const int dbg = [] { const char* e = getenv("VR_WW_DBG"); return e ? atoi(e) : 0; }();   // ablations (perf only)
+    a.in.dbg = dbg;
+    if (CB == 32 && MT == 64) ww_launch<32, 64>(a, st);
+    else if (CB == 64 && MT == 32) ww_launch<64, 32>(a, st);
+    else ww_launch<32, 32>(a, st);
+}
+
+}  // namespace vr
