@@ -50,6 +50,10 @@ BWD_CASES = [
     (1, 70, 10, 16, 96, 3, 1, 1, 1, 0, 0, 1.0),      # CoutPad 96, H not a multiple of the 4-row chunk, 16 columns
     (2, 33, 9, 20, 128, 3, 1, 1, 1, 0, 0, 1.0),      # odd H, W = 20 (partial 16-column chunk)
     (1, 16, 8, 32, 16, 3, 1, 1, 1, 0, 0, 1.0),       # 32 x 32 blocks, couts padded 16 -> 32
+    # plain 1x1: pixel-contiguous GEMM weight gradient (wgrad_gemm.hip)
+    (2, 40, 16, 32, 8, 1, 1, 1, 1, 0, 0, 1.0),
+    (1, 320, 16, 16, 128, 1, 1, 1, 1, 0, 0, 1.0),    # three 128-channel blocks, two 64-cout blocks
+    (2, 132, 8, 24, 72, 1, 1, 1, 1, 0, 0, 1.0),      # 192 pixels per sample (3 chunks), CoutPad 96
 ]
 
 

@@ -7,6 +7,7 @@
 //     dy = G * post * act'(y),  y = z*scale + shift
 //     dz = scale * (dy - mean(dy) - xhat * mean(dy*xhat))  =  kA*dy + kB*z + kC      (per channel)
 #include <cmath>
+#include <cstdlib>
 
 #include "kernels.h"
 
@@ -229,10 +230,85 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ dhi, int N, int C,
     glo[(long long)n * gN + (long long)c * gC + (long long)i * gH + j] += acc;
 }
 
+// LDS-tiled form for the large tensors: one workgroup = an 8 x 32 tile of low-resolution outputs of one (n, c) plane;
+// the (2*8+3) x (2*32+3) patch of the high-resolution gradient that can touch it is staged once (coalesced rows), the
+// 5 x 5 separable gather then runs out of LDS -- every dhi element is fetched from HBM once per tile instead of up to
+// 25 times through the caches.
+__global__ __launch_bounds__(256) void upsample_bwd_tiled_kernel(const float* __restrict__ dhi, int C, int H, int W, float rh,
+                                                                 float rw, int tiles_w, int tiles_per_plane,
+                                                                 float* __restrict__ glo, long long gN, long long gC,
+                                                                 long long gH) {
+    constexpr int TI = 8, TJ = 32, PH = 2 * TI + 3, PW = 2 * TJ + 3, PP = PW + 1;
+    __shared__ float patch[PH * PP];
+    const int plane = blockIdx.x / tiles_per_plane;          // n * C + c
+    const int trem = blockIdx.x - plane * tiles_per_plane;
+    const int i0 = (trem / tiles_w) * TI, j0 = (trem % tiles_w) * TJ;
+    const int H2 = 2 * H, W2 = 2 * W;
+    const float* src = dhi + (long long)plane * H2 * W2;
+    const int hb = 2 * i0 - 2, wb = 2 * j0 - 2;
+    for (int e = threadIdx.x; e < PH * PW; e += 256) {
+        const int r = e / PW, q = e - r * PW;
+        const int h = hb + r, w = wb + q;
+        patch[r * PP + q] = (h >= 0 && h < H2 && w >= 0 && w < W2) ? src[(long long)h * W2 + w] : 0.f;
+    }
+    __syncthreads();
+    const int ti = threadIdx.x >> 5, tj = threadIdx.x & 31;
+    const int i = i0 + ti, j = j0 + tj;
+    if (i >= H || j >= W) return;
+    float wh[5], ww[5];
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+        const int h = 2 * i - 2 + d;
+        float v = 0.f;
+        if (h >= 0 && h < H2) {
+            const float h1r = rh * (float)h;
+            const int h1 = (int)h1r;
+            const int h1p = (h1 < H - 1) ? 1 : 0;
+            const float l1 = h1r - (float)h1;
+            if (h1 == i) v += 1.f - l1;
+            if (h1 + h1p == i) v += l1;
+        }
+        wh[d] = v;
+        const int w = 2 * j - 2 + d;
+        float u = 0.f;
+        if (w >= 0 && w < W2) {
+            const float w1r = rw * (float)w;
+            const int w1 = (int)w1r;
+            const int w1p = (w1 < W - 1) ? 1 : 0;
+            const float m1 = w1r - (float)w1;
+            if (w1 == j) u += 1.f - m1;
+            if (w1 + w1p == j) u += m1;
+        }
+        ww[d] = u;
+    }
+    const float* pr = patch + (2 * ti) * PP + 2 * tj;
+    float acc = 0.f;
+#pragma unroll
+    for (int dh = 0; dh < 5; ++dh) {
+        float r = 0.f;
+#pragma unroll
+        for (int dw = 0; dw < 5; ++dw) r = fmaf(ww[dw], pr[dh * PP + dw], r);
+        acc = fmaf(wh[dh], r, acc);
+    }
+    const int n = plane / C, c = plane - n * C;
+    glo[(long long)n * gN + (long long)c * gC + (long long)i * gH + j] += acc;
+}
+
 void launch_upsample_bwd(const float* dhi, int N, int C, int H, int W, float* glo, long long gN, long long gC,
                          long long gH, hipStream_t st) {
     const long long total = (long long)N * C * H * W;
     const float rh = (float)(H - 1) / (float)(2 * H - 1), rw = (float)(W - 1) / (float)(2 * W - 1);
+    static const bool tiled = !getenv("VR_NO_UPBWD_TILED");
+    if (tiled && W >= 16 && H >= 4) {
+        const int tiles_w = (W + 31) / 32, tiles_h = (H + 7) / 8;
+        const long long blocks = (long long)N * C * tiles_h * tiles_w;
+        if (blocks < 0x7FFFFFFFLL) {
+            hipLaunchKernelGGL(upsample_bwd_tiled_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dhi, C, H, W, rh, rw, tiles_w,
+                               tiles_h * tiles_w, glo, gN, gC, gH);
+            VR_HIP(hipGetLastError());
+            return;
+        }
+    }
     hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dhi, N, C, H, W, rh, rw,
                        glo, gN, gC, gH);
     VR_HIP(hipGetLastError());

@@ -437,6 +437,9 @@ static WgTile wg_pick(const WgradArgs& a, const ConvShape& s) {
 bool wgrad_wino_pick(const WgradArgs& a, const ConvShape& s, int* CB_out, int* MT_out);     // wgrad_wino.hip
 void wgrad_wino_plan(WgradArgs& a, int CB, int MT);
 void wgrad_wino_launch(const WgradArgs& a, int CB, int MT, hipStream_t st);
+bool wgrad_gemm_pick(const WgradArgs& a, const ConvShape& s);                                   // wgrad_gemm.hip
+void wgrad_gemm_plan(WgradArgs& a);
+void wgrad_gemm_launch(const WgradArgs& a, hipStream_t st);
 
 void wgrad_plan(WgradArgs& a, const ConvShape& s) {
     const WgTile t = wg_pick(a, s);
@@ -509,6 +512,12 @@ double launch_wgrad(const WgradArgs& a_in, const ConvShape& s, float* grad_out, 
             return 2.0 * a.in.N * (double)a.in.Hout * a.in.Wout * (double)a.Cout * a.in.Cin * 9;
         }
     }
+    if (wgrad_gemm_pick(a, s)) {                           // 1x1: pixel-contiguous GEMM, LDS-DMA ring
+        wgrad_gemm_plan(a);
+        wgrad_gemm_launch(a, st);
+        wgrad_reduce(a, grad_out, accumulate, st);
+        return 2.0 * a.in.N * (double)a.in.Hout * a.in.Wout * (double)a.Cout * a.in.Cin;
+    }
     wgrad_plan(a, s);
     const WgTile t = wg_pick(a, s);
     {
@@ -556,6 +565,12 @@ size_t wgrad_scratch_floats(const WgradArgs& a_in, const ConvShape& s) {
     WgradArgs a = a_in;
     wgrad_plan(a, s);
     size_t need = (size_t)a.P * (size_t)a.part_stride;
+    if (s.KS == 1 && s.stride == 1 && (long long)a_in.in.Hout * a_in.in.Wout % 64 == 0) {
+        WgradArgs b = a_in;
+        wgrad_gemm_plan(b);
+        const size_t n = (size_t)b.P * (size_t)b.part_stride;
+        if (n > need) need = n;
+    }
     if (s.KS == 3 && s.stride == 1 && s.dil_h == 1 && s.dil_w == 1 && a_in.allow_wino) {
         for (int alt = 0; alt < 3; ++alt) {
             WgradArgs b = a_in;

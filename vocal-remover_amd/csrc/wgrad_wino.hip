@@ -31,7 +31,8 @@ namespace vr {
 template <int CB, int MT>
 struct WwCfg {
     static constexpr int TH = 4, TW = 16, KT = 16;                     // chunk: 4 x 16 output pixels = 2 x 8 Winograd tiles
-    static constexpr int XR = TH + 2, XS0 = 3, TWq = 24, CSX = XR * TWq;   // raw input rows start 4 columns left of the chunk
+    static constexpr int XR = TH + 2, XS0 = 3, TWq = 24, CSX = XR * TWq + 4;   // raw input rows start 4 columns left of the chunk;
+                                                                       // +4: pitch 148 spreads the 4 channels of a transform over the banks
     static constexpr int CSZ = TH * TW;                                // raw dz floats per cout
     static constexpr int KP = KT + 1;                                  // odd k pitch: 32 channels -> 32 banks
     static constexpr int XRAW = CB * CSX, ZRAW = MT * CSZ;
@@ -40,7 +41,7 @@ struct WwCfg {
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
     static constexpr int WM = MT / 32, WN = CB / 32;
     static constexpr int MP = 33;                                      // epilogue exchange pitch
-    static_assert(CSX == 36 * 4 && CSZ == 16 * 4, "piece counts below");
+    static_assert(XR * TWq == 36 * 4 && CSZ == 16 * 4, "piece counts below");
     static_assert(16 * 32 * MP <= LDS_FLOATS && LDS_BYTES <= 160 * 1024, "LDS");
 };
 
@@ -74,7 +75,9 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const WgradArgs a) {
 
     // ---- DMA of one chunk: this wave's input channels and couts ---------------------------------------------------
     const int xq_row = lane / 6, xq_c4 = lane % 6;                     // lanes 0..35: 16-B piece (row, column quad)
-    const int zq_cs = lane >> 4, zq_row = (lane >> 2) & 3, zq_c4 = lane & 3;
+    // dz: lane = piece * 4 + cout (piece = row * 4 + column quad): piece-major in LDS, so that the 4 couts of a transform
+    // and the two column halves of a quad land in 16 different bank pairs
+    const int zq_cs = lane & 3, zq_row = lane >> 4, zq_c4 = (lane >> 2) & 3;
     auto issue_chunk = [&](int pt) {
         const int n = pt / tiles_per_img;
         const int trem = pt - n * tiles_per_img;
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const WgradArgs a) {
             const bool ok = lane < 36 && hi >= 0 && hi < a.in.Hin && wi >= 0 && wi + 3 < a.in.Win;
 #pragma unroll
             for (int i = 0; i < CB / 8; ++i) {
-                const int cl = wave + 8 * i;
+                const int cl = (CB / 8) * wave + i;                    // consecutive channels: the transform's 4 are a pitch apart
                 const int ci = c0 + cl;
                 const bool live = ci < a.in.Cin;
                 const int cj = live ? ci : 0;
@@ -117,20 +120,40 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const WgradArgs a) {
     // ---- transforms of what this wave fetched: lane = (tile k, sub-channel) ---------------------------------------
     const int tk = lane & 15, tsub = lane >> 4;
     const int ti = tk >> 3, tj = tk & 7;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     auto transform = [&]() {
 #pragma unroll
         for (int i = 0; i < CB / 32; ++i) {                            // B^T x B of 4 input channels
-            const int cl = wave + 8 * (4 * i + tsub);
+            if (a.in.dbg & 8) break;
+            // Patch columns 1, 2 of tile tj are one aligned 8-byte LDS read; column 0 is column 2 of tile tj-1 and column 3
+            // is column 1 of tile tj+1 (DPP lane shifts, no LDS traffic); the row's first / last tile read their outer
+            // column themselves.  The LDS pipe is shared by the whole CU and the transform phase does not overlap MFMAs.
+            const int cl = (CB / 8) * wave + 4 * i + tsub;
             const float* xp = Xraw + cl * CSX + (2 * ti) * TWq + 2 * tj + XS0;
             float* V = Vs + cl * KP + tk;                              // + f * CB * KP
+            if ((a.in.dbg & 32) && lane >= 1) V = Vs + lane;          // (ablation: all stores of a lane to one address)
+            const bool edge = tj == 0 || tj == 7;
+            const int eoff = tj == 0 ? 0 : 3;
+            float d[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const f32x2 mid = *reinterpret_cast<const f32x2*>(xp + r * TWq + 1);
+                const float m1 = mid[0], m2 = mid[1];
+                d[r][1] = m1; d[r][2] = m2;
+                float e = 0.f;
+                if (edge) e = xp[r * TWq + eoff];
+                const float left = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m2), 0x111, 0xf, 0xf, false));    // row_shr:1
+                const float right = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m1), 0x101, 0xf, 0xf, false));   // row_shl:1
+                d[r][0] = tj == 0 ? e : left;
+                d[r][3] = tj == 7 ? e : right;
+            }
             float t[4][4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float d0 = xp[c], d1 = xp[TWq + c], d2 = xp[2 * TWq + c], d3 = xp[3 * TWq + c];
-                t[0][c] = d0 - d2;
-                t[1][c] = d1 + d2;
-                t[2][c] = d2 - d1;
-                t[3][c] = d1 - d3;
+                t[0][c] = d[0][c] - d[2][c];
+                t[1][c] = d[1][c] + d[2][c];
+                t[2][c] = d[2][c] - d[1][c];
+                t[3][c] = d[1][c] - d[3][c];
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -142,10 +165,15 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const WgradArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < MT / 32; ++i) {                            // G dz G^T of 4 couts
-            const int col = 4 * (wave + 8 * i) + tsub;
-            const float* zp = Zraw + col * CSZ + (2 * ti) * TW + 2 * tj;
+            if (a.in.dbg & 16) break;
+            const int j = wave + 8 * i;
+            const int col = 4 * j + tsub;
+            // piece-major raw layout of the group: float (piece q, cout, w) at q*16 + cout*4 + w, q = row*4 + (tj>>1)
+            const float* zp = Zraw + j * (4 * CSZ) + ((2 * ti) * 4 + (tj >> 1)) * 16 + tsub * 4 + 2 * (tj & 1);
             float* U = Us + col * KP + tk;                             // + f * MT * KP
-            const float g00 = zp[0], g01 = zp[1], g10 = zp[TW], g11 = zp[TW + 1];
+            const f32x2 g0 = *reinterpret_cast<const f32x2*>(zp);
+            const f32x2 g1 = *reinterpret_cast<const f32x2*>(zp + 4 * 16);
+            const float g00 = g0[0], g01 = g0[1], g10 = g1[0], g11 = g1[1];
             float t[4][2];
             t[0][0] = g00;                 t[0][1] = g01;
             t[1][0] = 0.5f * (g00 + g10);  t[1][1] = 0.5f * (g01 + g11);
