@@ -63,7 +63,11 @@ int vr_set_mode(vr_handle h, int training);
  * reference); 0 = direct kernels only.  Inference always uses Winograd where applicable.
  * "adam_reset": zero the Adam moments and the step counter (what constructing a new
  * torch.optim.Adam does; train.py:215-218).  "serial_exec" (default 0): 1 = every kernel on the handle's one
- * stream, no lanes / side streams (tests: results must not depend on the concurrent executor).            */
+ * stream, no lanes / side streams (tests: results must not depend on the concurrent executor).
+ * "mfma_bf16" (default 0; configs[4]): 1 = the Winograd convolutions (forward, data gradient, weight gradient) and
+ * the 1x1 weight-gradient GEMM round their MFMA operands to bf16 (RNE, in registers) and run on
+ * v_mfma_f32_32x32x8_bf16; accumulation, every stored tensor, the master weights and Adam stay fp32.
+ * "params_dirty": the parameter arena was written from outside (vr_param_arena).                              */
 int vr_set_option(vr_handle h, const char* name, int value);
 
 /* CascadedNet.forward (mode 0) / predict_mask (mode 1) / predict (mode 2)   lib/nets.py:82-141
@@ -100,6 +104,19 @@ int vr_separate_wave(vr_handle h, const float* wave, int wave_on_device, int64_t
  * may be NULL): the full-width mask [B,2,bins,T] that model(X) returns.  Needs vr_set_mode(h, 1).    */
 int vr_train_step(vr_handle h, const float* X, const float* y, int on_device, int B, int T, int accumulation_steps,
                   float* loss_out, float* mask_out, int mask_on_device);
+/* The same step as TWO calls, for callers that keep the reference's own loss expression and optimizer between them
+ * (train.py:81-95 unmodified: `mask = model(X)` ... `loss.backward()` ... `optimizer.step()`):
+ *   vr_forward_train   mask = model(X) under model.train(): batch-statistics BatchNorm (running buffers updated), live
+ *                      Dropout2d, the graph (raw activations) kept inside the handle.  mask_out [B,2,bins,T].
+ *   vr_backward        dmask = dLoss/dmask [B,2,bins,T] -> gradients ACCUMULATE in the gradient arena exactly like
+ *                      vr_train_step's.  Consumes the graph; any other call on the handle in between frees it (-2).
+ * vr_param_arena: the flat fp32 parameter arena (device pointer, element count; same indexing as vr_grad_arena), so
+ * that an element-wise optimizer from outside (torch.optim.Adam on a zero-copy view) can update the weights in place;
+ * call vr_set_option(h, "params_dirty", 1) after writing it so that eval-mode folded tables are rebuilt.            */
+int vr_forward_train(vr_handle h, const float* X, int on_device, int B, int T, float* mask_out, int mask_on_device);
+int vr_backward(vr_handle h, const float* dmask, int on_device);
+int vr_param_arena(vr_handle h, float** device_ptr, int64_t* numel);
+
 /* Training input pipeline on the device: replaces the numeric part of
  * lib/dataset.py VocalRemoverTrainingSet.__getitem__ (dataset.py:105-120) for a whole batch.
  *   X, y           [B][T][2][bins] complex64 (re,im interleaved): the cropsize rows read from the cached .npy files
@@ -121,6 +138,10 @@ int vr_augment_batch(vr_handle h, const float* X, const float* y, const float* X
  * then rounded to the fp32 the parameters live in (1 - 0.999f differs from 0.001f by 1.3e-5 relative).          */
 int vr_adam_step(vr_handle h, double lr, double b1, double b2, double eps, double grad_scale);
 int vr_zero_grad(vr_handle h);                                          /* model.zero_grad(), train.py:96 */
+/* optimizer.state_dict() / load_state_dict() for a resumable checkpoint (the reference saves the model only,
+ * train.py:290): the Adam moments as flat host arrays of vr_grad_arena's element count (arena order) + the step. */
+int vr_get_adam_state(vr_handle h, float* exp_avg, float* exp_avg_sq, int64_t numel, int64_t* step);
+int vr_set_adam_state(vr_handle h, const float* exp_avg, const float* exp_avg_sq, int64_t numel, int64_t step);
 int vr_get_grad(vr_handle h, const char* key, float* host, int64_t capacity_bytes);   /* param.grad, torch layout */
 /* nn.Dropout2d(0.1) on the five ASPP outputs (lib/layers.py:90), live in train mode.  mode 1 (the DEFAULT, as in
  * the reference): device-side counter-based generator keyed on (seed, number of train-mode forwards so far), a
@@ -154,6 +175,15 @@ int vr_allreduce_grads(vr_handle h, int wire_dtype);
 /* Rank `root`'s parameters, BatchNorm buffers and num_batches_tracked (and, with_optimizer != 0, the Adam moments and
  * step count) replace every rank's: replicas start identical (what DistributedDataParallel does at construction). */
 int vr_broadcast_params(vr_handle h, int root, int with_optimizer);
+
+/* ---- audio front end (no model handle, `device` = GPU index, host pointers) ----------------
+ * vr_resample: the resampling step of librosa.load(path, sr=sr_out, res_type='kaiser_fast')   inference.py:136-138,
+ * lib/spec_utils.py:139-142.  x [channels][n_in] at sr_in -> y [channels][n_out], n_out = ceil(n_in * sr_out / sr_in)
+ * (librosa's fix_length: resampy yields int(n_in * ratio) samples, the rest is zero).  resampy~=0.4 is a third-party
+ * dependency of the reference that is not vendored: its published 'kaiser_fast' filter is restated (parity unpinned).
+ * vr_xcorr_argmax: np.argmax(np.correlate(a, b, 'full'))        lib/spec_utils.py:107-108 (align_wave_head_and_tail). */
+int vr_resample(int device, const float* x, int channels, int64_t n_in, int sr_in, int sr_out, float* y, int64_t n_out);
+int vr_xcorr_argmax(int device, const float* a, int64_t na, const float* b, int64_t nb, int64_t* argmax_out);
 
 /* ---- measurement hooks (bench.py) ----------------------------------------------------------- */
 /* Bracket subsequent calls: every MFMA-conv launch is timed with HIP events on the handle's stream.

@@ -224,7 +224,7 @@ def test_train_mode_forward_uses_and_updates_batch_statistics(vr, small):
     model.train()
     model.set_dropout_masks(None)
     X, y = train_step.synth_batch(5, T=160, n_fft=512, seed=21)
-    mask = model(X[:2].to('cuda:0')).cpu().numpy()
+    mask = model(X[:2].to('cuda:0')).detach().cpu().numpy()      # (differentiable under model.train(), like the reference's)
     assert np.abs(mask[:, :, ::7] - GV['train_fwd_mask']).max() < 1e-4
     after = model.state_dict()
     for key in GV.files:
@@ -237,20 +237,21 @@ def test_train_mode_forward_uses_and_updates_batch_statistics(vr, small):
     fresh.load_state_dict(sd)
     fresh.to(torch.device('cuda:0'))
     fresh.set_dropout_masks(None)
-    m1 = fresh(X[:2].to('cuda:0')).cpu().numpy()
+    m1 = fresh(X[:2].to('cuda:0')).detach().cpu().numpy()
     assert np.abs(m1 - mask).max() < 1e-6
     fresh.load_state_dict(sd)
     fresh.zero_grad()
     loss = fresh.train_step(X[:2], y[:2], 1)
     assert np.isfinite(loss)
-    m2 = fresh(X[2:4].to('cuda:0')).cpu().numpy()                            # after a train step: no stale tape / arena
+    with torch.no_grad():                                                    # the tape-free train-mode forward (vr_forward)
+        m2 = fresh(X[2:4].to('cuda:0')).cpu().numpy()                        # after a train step: no stale tape / arena
     assert np.isfinite(m2).all() and m2.shape == (2, 2, 257, 160)
     # dropout is live by default in train mode (lib/layers.py:90): two forwards differ, eval does not
     live = vr.nets.CascadedNet(512, 256, 8, 32)
     live.load_state_dict(sd)
     live.to(torch.device('cuda:0'))
-    a = live(X[:2].to('cuda:0')).cpu().numpy()
-    b = live(X[:2].to('cuda:0')).cpu().numpy()
+    a = live(X[:2].to('cuda:0')).detach().cpu().numpy()
+    b = live(X[:2].to('cuda:0')).detach().cpu().numpy()
     assert np.abs(a - b).max() > 1e-6
     live.eval()
     c, d = live(X[:2].to('cuda:0')).cpu().numpy(), live(X[:2].to('cuda:0')).cpu().numpy()

@@ -312,3 +312,70 @@ def test_train_step_shape_sweep_loss_and_a_gradient(small_train, B, T):
     g = model.grads(keys={'out.weight', 'stg3_full_band_net.dec1.conv1.conv.0.weight'})
     for k in g:
         assert _rel(g[k], g32[k]) < 5e-2, (k, _rel(g[k], g32[k]))
+
+
+# ---- configs[4]: bf16 operands on the matrix pipe (vr_set_option "mfma_bf16"), fp32 storage / accumulation / master weights ----
+def test_bf16_mfma_mode_train_step_tracks_fp32(vr, small_train):
+    """Same step with bf16 MFMA operands in the Winograd convolutions and the 1x1 weight-gradient GEMM.  Stated tolerance:
+    loss within 2e-3 relative of the fp32 path; every gradient tensor with >= 64 elements has cosine similarity > 0.98 with
+    its fp32 counterpart and a norm within 10 % (bf16 keeps 8 mantissa bits; the Winograd transforms are rounded too)."""
+    model, sd = small_train
+    X, y = train_step.synth_batch(4, T=128, n_fft=N_FFT, seed=5)
+    Xd, yd = X.to('cuda:0'), y.to('cuda:0')
+    out = {}
+    for mode in (0, 1):
+        model.load_state_dict(sd)
+        model.train()
+        model.set_dropout_masks(None)
+        model.set_option('mfma_bf16', mode)
+        model.zero_grad()
+        loss = model.train_step(Xd, yd, 1)
+        out[mode] = (loss, model.grads())
+    model.set_option('mfma_bf16', 0)
+    l32, g32 = out[0]
+    l16, g16 = out[1]
+    assert l16 != l32 and abs(l16 - l32) < 2e-3 * abs(l32), (l16, l32)
+    cos = []
+    for k in g32:
+        a, b = g32[k].double().flatten(), g16[k].double().flatten()
+        if a.numel() < 64 or float(a.norm()) < 1e-9:
+            continue
+        c = float((a @ b) / (a.norm() * b.norm()))
+        cos.append((c, k))
+        assert c > 0.98, (k, c)
+        assert abs(float(b.norm() / a.norm()) - 1) < 0.1, k
+    print('bf16 MFMA mode: loss %.7f vs fp32 %.7f; worst gradient cosine %.5f (%s)' % ((l16, l32) + min(cos)))
+
+
+def test_bf16_mfma_mode_single_convs(vr, small_train):
+    """One Winograd conv and one 1x1 weight gradient in bf16-operand mode against torch fp32: <= 2e-2 of the output scale."""
+    model, _ = small_train
+    nat = vr.native
+    model.set_option('mfma_bf16', 1)
+    try:
+        g = torch.Generator().manual_seed(0)
+        N, Cin, H, W, Cout = 1, 40, 24, 64, 64
+        x = torch.randn(N, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+        want = F.conv2d(x, w, None, 1, 1)
+        out = np.empty(tuple(want.shape), np.float32)
+        nat.check(nat.lib().vr_debug_conv2d(model._handle.h, nat.np_ptr(x.numpy()), N, Cin, H, W, nat.np_ptr(w.numpy()), Cout, 3, 1, 1, 1,
+                                            2, None, ctypes.c_float(1.0), None, nat.np_ptr(out), None))
+        e = float(np.abs(out - want.numpy()).max() / want.abs().max())
+        assert 1e-5 < e < 2e-2, e                      # really bf16 (not the fp32 path), and within bf16 accuracy
+        for (N, Cin, H, W, Cout, ks) in ((1, 40, 24, 64, 64, 3), (2, 40, 16, 32, 8, 1)):
+            x = torch.randn(N, Cin, H, W, generator=g)
+            wt = (torch.randn(Cout, Cin, ks, ks, generator=g) / (Cin * ks * ks) ** 0.5).requires_grad_(True)
+            xin = x.clone().requires_grad_(True)
+            o = F.conv2d(xin, wt, None, 1, ks // 2)
+            dz = torch.randn(o.shape, generator=g)
+            o.backward(dz)
+            dx = np.empty(tuple(x.shape), np.float32)
+            dw = np.empty(tuple(wt.shape), np.float32)
+            nat.check(nat.lib().vr_debug_conv2d_backward(model._handle.h, nat.np_ptr(x.numpy()), N, Cin, H, W, nat.np_ptr(wt.detach().numpy()),
+                                                         Cout, ks, 1, 1, 1, 0, None, ctypes.c_float(1.0), nat.np_ptr(dz.numpy()),
+                                                         nat.np_ptr(dx), nat.np_ptr(dw)))
+            ew = float(np.abs(dw - wt.grad.numpy()).max() / wt.grad.abs().max())
+            assert 1e-6 < ew < 2e-2, (ks, ew)
+    finally:
+        model.set_option('mfma_bf16', 0)

@@ -11,6 +11,6 @@ there is no CPU / PyTorch fallback.  `dropin/` holds a `lib` package + `inferenc
 the reference's modules so its scripts run unchanged.
 """
 from . import native  # noqa: F401
-from . import dataset, inference, nets, spec_utils  # noqa: F401
+from . import audio, dataset, inference, nets, spec_utils  # noqa: F401
 
-__all__ = ['native', 'nets', 'spec_utils', 'dataset', 'inference']
+__all__ = ['native', 'nets', 'spec_utils', 'dataset', 'inference', 'audio']

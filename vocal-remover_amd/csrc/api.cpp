@@ -6,6 +6,11 @@
 
 #include "model.h"
 
+namespace vr {
+void resample_api(int device, const float* x, int channels, long long n_in, int sr_in, int sr_out, float* y, long long n_out);
+void xcorr_argmax_api(int device, const float* a, long long na, const float* b, long long nb, long long* argmax_out);
+}  // namespace vr
+
 struct vr_model {
     vr::Model m;
     vr_model(int d, int n, int h, int o, int l) : m(d, n, h, o, l) {}
@@ -164,6 +169,27 @@ int vr_train_step(vr_handle h, const float* X, const float* y, int on_device, in
     });
 }
 
+int vr_forward_train(vr_handle h, const float* X, int on_device, int B, int T, float* mask_out, int mask_on_device) {
+    NEED(h);
+    return guard([&] {
+        VR_CHECK(X && mask_out, VR_ERR_BAD_ARGUMENT, "null argument");
+        h->m.forward_train_api(X, on_device != 0, B, T, mask_out, mask_on_device != 0);
+    });
+}
+
+int vr_backward(vr_handle h, const float* dmask, int on_device) {
+    NEED(h);
+    return guard([&] { h->m.backward_api(dmask, on_device != 0); });
+}
+
+int vr_param_arena(vr_handle h, float** device_ptr, int64_t* numel) {
+    NEED(h);
+    return guard([&] {
+        VR_CHECK(device_ptr && numel, VR_ERR_BAD_ARGUMENT, "null argument");
+        h->m.param_arena(device_ptr, numel);
+    });
+}
+
 int vr_augment_batch(vr_handle h, const float* X, const float* y, const float* X_mix, const float* y_mix, const vr_aug* desc,
                      const float* reduction_weight, int B, int T, int bins, int in_on_device, float* X_mag, float* y_mag,
                      int out_on_device) {
@@ -185,6 +211,23 @@ int vr_augment_batch(vr_handle h, const float* X, const float* y, const float* X
 int vr_adam_step(vr_handle h, double lr, double b1, double b2, double eps, double grad_scale) {
     NEED(h);
     return guard([&] { h->m.adam_step_api(lr, b1, b2, eps, grad_scale); });
+}
+
+int vr_get_adam_state(vr_handle h, float* exp_avg, float* exp_avg_sq, int64_t numel, int64_t* step) {
+    NEED(h);
+    return guard([&] {
+        VR_CHECK(exp_avg && exp_avg_sq && step, VR_ERR_BAD_ARGUMENT, "null argument");
+        h->m.adam_state(exp_avg, exp_avg_sq, numel, step, false);
+    });
+}
+
+int vr_set_adam_state(vr_handle h, const float* exp_avg, const float* exp_avg_sq, int64_t numel, int64_t step) {
+    NEED(h);
+    return guard([&] {
+        VR_CHECK(exp_avg && exp_avg_sq, VR_ERR_BAD_ARGUMENT, "null argument");
+        int64_t st = step;
+        h->m.adam_state(const_cast<float*>(exp_avg), const_cast<float*>(exp_avg_sq), numel, &st, true);
+    });
 }
 
 int vr_zero_grad(vr_handle h) {
@@ -254,6 +297,31 @@ int vr_debug_kernel(vr_handle h, const char* name, const int64_t* dims, int ndim
     return guard([&] {
         VR_CHECK(name && dims && inputs && outputs, VR_ERR_BAD_ARGUMENT, "null argument");
         h->m.debug_kernel(name, dims, ndims, fparams, nfparams, inputs, ninputs, outputs, noutputs);
+    });
+}
+
+static void need_device(int device) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        throw vr::Error(VR_ERR_HIP, "no HIP device visible: libvr_mi355 has no CPU fallback");
+    if (device < 0 || device >= count) throw vr::Error(VR_ERR_BAD_ARGUMENT, "device index out of range");
+}
+
+int vr_resample(int device, const float* x, int channels, int64_t n_in, int sr_in, int sr_out, float* y, int64_t n_out) {
+    return guard([&] {
+        VR_CHECK(x && y, VR_ERR_BAD_ARGUMENT, "null argument");
+        need_device(device);
+        vr::resample_api(device, x, channels, n_in, sr_in, sr_out, y, n_out);
+    });
+}
+
+int vr_xcorr_argmax(int device, const float* a, int64_t na, const float* b, int64_t nb, int64_t* argmax_out) {
+    return guard([&] {
+        VR_CHECK(a && b && argmax_out, VR_ERR_BAD_ARGUMENT, "null argument");
+        need_device(device);
+        long long best = 0;
+        vr::xcorr_argmax_api(device, a, na, b, nb, &best);
+        *argmax_out = best;
     });
 }
 

@@ -529,6 +529,31 @@ __global__ __launch_bounds__(256) void head_loss_kernel(Tensor x, const float* _
     if (threadIdx.x == 0) loss_part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// Backward of the mask head alone (the autograd split of train.py:81,92): dmask [N][2][bins][W] = dLoss/d(mask), mask
+// [N][2][bins][W] = the forward's sigmoid output  ->  dlogit [N][2][H][W] = m (1 - m) * (sum over the replicate-padded
+// rows that share the logit of row H-1).
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dmask, const float* __restrict__ mask, int N,
+                                                       int H, int W, int bins, float* __restrict__ dlogit) {
+    const long long total = (long long)N * 2 * H * W;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int w = (int)(gid % W);
+    long long t = gid / W;
+    const int h = (int)(t % H);
+    const long long no = t / H;                  // n * 2 + o
+    const long long off = (no * bins + h) * W + w;
+    const float m = mask[off];
+    float d = dmask[off];
+    if (h == H - 1)
+        for (int e = 1; e <= bins - H; ++e) d += dmask[off + (long long)e * W];
+    dlogit[gid] = d * m * (1.f - m);
+}
+void launch_head_bwd(const float* dmask, const float* mask, int N, int H, int W, int bins, float* dlogit, hipStream_t st) {
+    const long long total = (long long)N * 2 * H * W;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dmask, mask, N, H, W, bins, dlogit);
+    VR_HIP(hipGetLastError());
+}
+
 int head_loss_blocks(const Tensor& x) { return (int)(((long long)x.N * x.H * x.W + 255) / 256); }
 
 void launch_head_loss(const Tensor& x, const float* w, const float* X, const float* Y, int bins, float gscale,

@@ -12,6 +12,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float act_apply(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+// ---- bf16 matrix pipe with fp32 storage ("mfma_bf16" option, configs[4]): operands are rounded to bf16 (RNE) in
+// registers right before the MFMA, products accumulate in fp32.  v_mfma_f32_32x32x8_bf16: lane (row/col = lane & 31,
+// kgroup = lane >> 5) supplies the 4 operands k = 4*kgroup .. 4*kgroup+3; 8 passes for 4x the k of the fp32 instruction.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4 pack_bf16x4(float a, float b, float c, float d) {
+    unsigned lo, hi;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(c), "v"(d));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 u; u[0] = lo; u[1] = hi;
+    return __builtin_bit_cast(s16x4, u);
+}
+__device__ __forceinline__ f32x16 mfma_bf16(s16x4 a, s16x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, b, c, 0, 0, 0);
+}
+
 // Fields of a.src[si] for a wave-uniform si, selected one by one with scalar selects: indexing the
 // by-value kernel argument dynamically makes the compiler keep a copy of it in scratch memory.
 struct SrcSel {

@@ -175,7 +175,29 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
         if (k + 1 < nchunk) issue_chunk(k + 1);
         const float* Ws = WsB + (k & 1) * Cfg::WS + (2 * wave) * CK * MT + aoff;
         const float* Vs = VsB + (k % Cfg::NVB) * Cfg::VS + (2 * wave) * CK * NT + boff;
-        if (a.dbg != 2) {
+        if (a.bf16) {
+            // bf16 operands: one v_mfma_f32_32x32x8_bf16 covers the chunk's 8 input channels of a frequency
+            const float* Wb = WsB + (k & 1) * Cfg::WS + (2 * wave) * CK * MT + (4 * khalf) * MT + l31;
+            const float* Vb = VsB + (k % Cfg::NVB) * Cfg::VS + (2 * wave) * CK * NT + (4 * khalf) * NT + l31;
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi) {
+                s16x4 A[WM], B[2];
+#pragma unroll
+                for (int mi = 0; mi < WM; ++mi) {
+                    const float* q = Wb + fi * CK * MT + mi * 32;
+                    A[mi] = pack_bf16x4(q[0], q[MT], q[2 * MT], q[3 * MT]);
+                }
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const float* q = Vb + fi * CK * NT + ni * 32;
+                    B[ni] = pack_bf16x4(q[0], q[NT], q[2 * NT], q[3 * NT]);
+                }
+#pragma unroll
+                for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) acc[fi][mi][ni] = mfma_bf16(A[mi], B[ni], acc[fi][mi][ni]);
+            }
+        } else if (a.dbg != 2) {
             // 8 k-steps (2 frequencies x 4 channel pairs), operands of step s+1 read before the MFMAs of step s
             float av[WM], bv[2];
 #pragma unroll

@@ -99,6 +99,7 @@ void launch_reduce_rows(const float* part, long long stride, int P, float* out, 
 int head_loss_blocks(const Tensor& x);
 void launch_head_loss(const Tensor& x, const float* w, const float* X, const float* Y, int bins, float gscale,
                       float* dlogit, float* mask_out, float* loss_part, float* loss_out, float loss_scale, hipStream_t st);
+void launch_head_bwd(const float* dmask, const float* mask, int N, int H, int W, int bins, float* dlogit, hipStream_t st);
 struct FlipDesc { const float* w; float* wt; int Cin, Cout, KK, CinPad, CoutPad; };
 void launch_flip_transpose(const FlipDesc* d_descs, int n, hipStream_t st);
 void launch_adam(float* p, const float* g, float* m, float* v, long long n, double lr, double b1, double b2, double eps,

@@ -147,6 +147,7 @@ public:
                      int B, int T, int bins, bool in_on_dev, float* Xmag, float* ymag, bool out_on_dev);
     char* aug_buf = nullptr; size_t aug_cap = 0;         // staging of the training input pipeline
     bool train_wino = true;                              // vr_set_option("train_winograd"): Winograd kernels in train mode
+    bool mfma_bf16 = false;                              // vr_set_option("mfma_bf16"): bf16 operands on the matrix pipe (configs[4])
     bool serial = false;                                 // vr_set_option("serial_exec"): no lanes / side streams (tests: race detector)
     void set_option(const std::string& name, int value);
     void reset_adam_state();
@@ -253,8 +254,15 @@ public:
     // train.py:77-96: forward (train mode) + L1 loss + backward; gradients accumulate in the arena.
     void train_fwd_bwd_api(const float* X, const float* Y, bool on_dev, int B, int T, int accumulation_steps,
                            float* loss_out, float* mask_out, bool mask_on_dev);
+    // the same step as two calls (autograd split): forward that keeps the graph, backward from dLoss/dmask
+    void forward_train_api(const float* X, bool on_dev, int B, int T, float* mask_out, bool mask_on_dev);
+    void backward_api(const float* dmask, bool on_dev);
+    bool graph_valid = false; int graph_B = 0, graph_T = 0; Tensor graph_f3; float* graph_mask = nullptr;
+    void param_arena(float** ptr, int64_t* numel) { *ptr = p_arena; *numel = (int64_t)p_floats; }
+    void mark_params_dirty() { affine_dirty = true; }
     void adam_step_api(double lr, double b1, double b2, double eps, double grad_scale);
     void zero_grad_api();
+    void adam_state(float* m_host, float* v_host, int64_t numel, int64_t* step, bool set);
     void get_grad(const std::string& key, float* host, int64_t cap_bytes);
     void set_dropout(int mode, unsigned long long seed, const float* masks, int B);
     void grad_arena(float** ptr, int64_t* numel);

@@ -334,6 +334,8 @@ void Model::fold_eval_affines() {
 void Model::set_option(const std::string& name, int value) {
     if (name == "train_winograd") train_wino = value != 0;
     else if (name == "serial_exec") serial = value != 0;     // every kernel on the handle's one stream (race detector of the tests)
+    else if (name == "params_dirty") affine_dirty = true;    // the parameter arena was written from outside (vr_param_arena)
+    else if (name == "mfma_bf16") mfma_bf16 = value != 0;    // bf16 operands on the matrix pipe, fp32 storage / accumulation
     else if (name == "adam_reset") reset_adam_state();      // a freshly constructed torch.optim.Adam has no moments
     else throw Error(-2, "unknown option: " + name);
 }
@@ -565,6 +567,7 @@ Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs_in, int N, cons
     const bool fuse_epi = !training && L.bn != nullptr;
     if (fuse_epi) { a.epi = L.bn->affine; a.epi_slope = L.slope; }
     a.wino = (training && !train_wino) ? nullptr : L.wino;   // (null until the first refresh_wino())
+    a.bf16 = mfma_bf16 ? 1 : 0;
     Tensor o;
     if (batch_as_h) {
         o.N = N; o.C = L.Cout; o.H = 1; o.W = a.Wout;
@@ -867,6 +870,7 @@ Tensor Model::run_net(const Tensor& x) {
 }
 
 void Model::plan_and_reserve(int B, int T, size_t extra_bytes) {
+    graph_valid = false;                         // the workspace is about to be rewound: a kept training graph dies here
     // the dry run is pure host work (~0.3 ms for the full net): remember its result per (B, T, mode)
     if (plan_B == B && plan_T == T && plan_training == training && plan_peak > 0) {
         ensure_ws(plan_peak + extra_bytes + 4096);
@@ -1303,6 +1307,7 @@ void Model::debug_conv(const float* x, int N, int Cin, int H, int W, const float
     a.nsrc = 1; a.src[0] = make_src(t, up != 0, 0); a.c1 = a.c2 = Cin; a.Cin = Cin;
     a.w = dw_; a.bias = dbias; a.Cout = Cout; a.CoutPad = CoutPad;
     if (epi && daff) { a.epi = daff; a.epi_slope = slope; }
+    a.bf16 = mfma_bf16 ? 1 : 0;
     float* dwino = nullptr;
     if (want_wino) {
         VR_CHECK(KS == 3 && stride == 1 && dh == 1 && dw == 1, -2, "Winograd weights exist for 3x3 stride-1 convs only");

@@ -166,6 +166,7 @@ void Model::bwd_conv(TapeRec& r) {
         else { w.zN = out.sN; w.zC = out.sC; w.zH = out.sH; }
         w.Cout = L.Cout; w.CoutPad = L.CoutPad;
         w.allow_wino = train_wino ? 1 : 0;
+        w.bf16 = mfma_bf16 ? 1 : 0;
         w.part = ws.allocf(wgrad_scratch_floats(w, shp));
         if (!dry) {
             // The weight gradient is off the critical path (dz -> data gradient -> previous layer): it runs on the
@@ -202,6 +203,7 @@ void Model::bwd_conv(TapeRec& r) {
         d.wino = (!dry && train_wino && it != winot_of.end()) ? it->second : nullptr;
     }
     d.bias = nullptr;
+    d.bf16 = mfma_bf16 ? 1 : 0;
     d.Cout = L.Cin; d.CoutPad = round_up32(L.Cin);
     d.N = f.N; d.Hin = f.Hin; d.Win = f.Win; d.Hout = f.Hin; d.Wout = f.Win;
     d.pad_h = (L.KS == 1) ? 0 : L.dh; d.pad_w = (L.KS == 1) ? 0 : L.dw;
@@ -366,6 +368,7 @@ void Model::train_fwd_bwd_api(const float* X, const float* Y, bool on_dev, int B
                               float* loss_out, float* mask_out, bool mask_on_dev) {
     DeviceGuard dev_guard(device);
     VR_CHECK(training, -2, "train step needs train mode: call vr_set_mode(h, 1) (model.train(), train.py:69)");
+    graph_valid = false;
     VR_CHECK(B > 0 && accumulation_steps > 0, -2, "batch and accumulation_steps must be positive");
     VR_CHECK(T > 0 && T % 16 == 0, -5, "h1_shape[3] must be greater than h2_shape[3] (frames must be a multiple of 16)");
     ensure_train_state();
@@ -451,6 +454,108 @@ void Model::train_fwd_bwd_api(const float* X, const float* Y, bool on_dev, int B
     dropout_dev = nullptr;
 }
 
+// ---- the autograd split of the same step: `mask = model(X)` keeps the graph, `loss.backward()` comes later with
+// dLoss/dmask (train.py:81,92 as two calls, so that the reference's own loss expression and torch's own optimizer can
+// sit in between).  The graph lives in the workspace arenas: any other call on the handle invalidates it. ------------
+void Model::forward_train_api(const float* X, bool on_dev, int B, int T, float* mask_out, bool mask_on_dev) {
+    DeviceGuard dev_guard(device);
+    VR_CHECK(training, -2, "forward with a graph needs train mode: call vr_set_mode(h, 1) (model.train(), train.py:69)");
+    VR_CHECK(B > 0, -2, "batch must be positive");
+    VR_CHECK(T > 0 && T % 16 == 0, -5, "h1_shape[3] must be greater than h2_shape[3] (frames must be a multiple of 16)");
+    VR_CHECK(mask_out != nullptr, -2, "null argument");
+    graph_valid = false;
+    ensure_train_state();
+    launch_flip_transpose(d_flip, n_flip, stream);
+    for (Conv* L : s2_list) launch_s2_class_weights(L->w->dev, s2w_of[L->w], L->Cin, L->Cout, L->CoutPad, round_up32(L->Cin), stream);
+    refresh_wino(true);
+    const size_t io_floats = (size_t)B * 2 * output_bin * T;
+    const int Hm = max_bin;
+    auto fwd = [&](const float* xd) {
+        tape.clear();
+        Tensor xt;
+        xt.p = const_cast<float*>(xd); xt.N = B; xt.C = 2; xt.H = Hm; xt.W = T;
+        xt.sH = T; xt.sC = (long long)output_bin * T; xt.sN = 2 * xt.sC; xt.slope = 1.f;
+        return run_net(xt);
+    };
+    auto bwd_scratch = [&](const Tensor& f3) {       // the allocations backward_api makes, in its order
+        ws.allocf((size_t)B * 2 * Hm * T);
+        ws.allocf((size_t)thin_wgrad_blocks(f3) * 2 * f3.C);
+    };
+    {   // plan: dry run of forward + backward sizes both arenas
+        Arena sws = ws, sgs = gs;
+        ws.dry = gs.dry = true; ws.base = gs.base = nullptr; ws.off = gs.off = 0; ws.peak = gs.peak = 0;
+        dry = true;
+        try {
+            ws.allocf(3 * io_floats + 64);
+            Tensor f3 = fwd(reinterpret_cast<float*>(uintptr_t(256)));
+            bwd_scratch(f3);
+            backward();
+        } catch (...) { dry = false; ws = sws; gs = sgs; tape.clear(); throw; }
+        dry = false;
+        const size_t need_ws = ws.peak + 8192, need_gs = gs.peak + 4096;
+        ws = sws; gs = sgs;
+        ensure_ws(need_ws);
+        if (need_gs > gs.cap) {
+            VR_HIP(hipStreamSynchronize(stream));
+            if (gs.base) VR_HIP(hipFree(gs.base));
+            gs.base = nullptr; gs.cap = 0;
+            VR_HIP(hipMalloc(reinterpret_cast<void**>(&gs.base), need_gs + (need_gs >> 4)));
+            gs.cap = need_gs + (need_gs >> 4);
+        }
+        ws.reset(); gs.reset();
+        if (gs_clear_pending) { VR_HIP(hipStreamWaitEvent(stream, lanes[0].join, 0)); gs_clear_pending = false; }
+        VR_HIP(hipMemsetAsync(gs.base, 0, need_gs, stream));
+    }
+    prepare_dropout(B);
+    float* xd = ws.allocf(io_floats);
+    graph_mask = ws.allocf(io_floats);
+    ws.allocf(io_floats + 64);                                     // (keeps the dry run's offsets)
+    VR_HIP(hipMemcpyAsync(xd, X, io_floats * sizeof(float), on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
+    graph_f3 = fwd(xd);
+    HeadDst d{};
+    d.p = graph_mask; d.dH = T; d.dC = (long long)output_bin * T; d.dN = 2 * d.dC;
+    d.w_lo = 0; d.w_hi = T; d.pad_rows = output_bin - max_bin;
+    launch_head_sigmoid(graph_f3, out_w->dev, d, stream);
+    VR_HIP(hipMemcpyAsync(mask_out, graph_mask, io_floats * sizeof(float), mask_on_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
+    VR_HIP(hipStreamSynchronize(stream));
+    graph_valid = true; graph_B = B; graph_T = T;
+    affine_dirty = true;
+}
+
+void Model::backward_api(const float* dmask, bool on_dev) {
+    DeviceGuard dev_guard(device);
+    VR_CHECK(graph_valid, -2, "vr_backward: no graph -- call vr_forward_train first (another call on the handle in between frees it)");
+    VR_CHECK(dmask != nullptr, -2, "null argument");
+    graph_valid = false;
+    const int B = graph_B, T = graph_T, Hm = max_bin;
+    const size_t io_floats = (size_t)B * 2 * output_bin * T;
+    const Tensor& f3 = graph_f3;
+    const float* dm = dmask;
+    if (!on_dev) {                                                 // the input copy of the forward is dead by now: reuse nothing, stage after the tape
+        float* tmp = nullptr;
+        VR_HIP(hipMalloc(&tmp, io_floats * sizeof(float)));
+        struct Free { float* p; hipStream_t s; ~Free() { hipStreamSynchronize(s); hipFree(p); } } fr{tmp, stream};
+        VR_HIP(hipMemcpyAsync(tmp, dmask, io_floats * sizeof(float), hipMemcpyHostToDevice, stream));
+        float* dlogit = ws.allocf((size_t)B * 2 * Hm * T);
+        float* wpart = ws.allocf((size_t)thin_wgrad_blocks(f3) * 2 * f3.C);
+        launch_head_bwd(tmp, graph_mask, B, Hm, T, output_bin, dlogit, stream);
+        launch_thin_wgrad(f3, 2, dlogit, wpart, grad_of(out_w), 1, stream);
+        launch_thin_dgrad(f3, 2, out_w->dev, dlogit, f3.g, 1, stream);
+        backward();
+        VR_HIP(hipStreamSynchronize(stream));
+    } else {
+        float* dlogit = ws.allocf((size_t)B * 2 * Hm * T);
+        float* wpart = ws.allocf((size_t)thin_wgrad_blocks(f3) * 2 * f3.C);
+        launch_head_bwd(dm, graph_mask, B, Hm, T, output_bin, dlogit, stream);
+        launch_thin_wgrad(f3, 2, dlogit, wpart, grad_of(out_w), 1, stream);
+        launch_thin_dgrad(f3, 2, out_w->dev, dlogit, f3.g, 1, stream);
+        backward();
+        VR_HIP(hipStreamSynchronize(stream));
+    }
+    tape.clear();
+    dropout_dev = nullptr;
+}
+
 // Training input pipeline (lib/dataset.py:105-120 after the random draws and the file reads), see augment.hip.
 void Model::augment_api(const float* Xc, const float* yc, const float* Xi, const float* yi, const void* desc, const float* rw,
                         int B, int T, int bins, bool in_on_dev, float* Xmag, float* ymag, bool out_on_dev) {
@@ -512,6 +617,22 @@ void Model::adam_step_api(double lr, double b1, double b2, double eps, double gr
     launch_adam(p_arena, g_arena, m_arena, v_arena, (long long)p_floats, lr, b1, b2, eps, adam_step, grad_scale, stream);
     VR_HIP(hipStreamSynchronize(stream));
     affine_dirty = true;
+}
+
+void Model::adam_state(float* m_host, float* v_host, int64_t numel, int64_t* step, bool set) {
+    DeviceGuard dev_guard(device);
+    ensure_train_state();
+    VR_CHECK(numel == (int64_t)p_floats, -2, "adam state: element count must equal vr_grad_arena's");
+    VR_HIP(hipStreamSynchronize(stream));
+    if (set) {
+        VR_HIP(hipMemcpy(m_arena, m_host, p_floats * sizeof(float), hipMemcpyHostToDevice));
+        VR_HIP(hipMemcpy(v_arena, v_host, p_floats * sizeof(float), hipMemcpyHostToDevice));
+        adam_step = *step;
+    } else {
+        VR_HIP(hipMemcpy(m_host, m_arena, p_floats * sizeof(float), hipMemcpyDeviceToHost));
+        VR_HIP(hipMemcpy(v_host, v_arena, p_floats * sizeof(float), hipMemcpyDeviceToHost));
+        *step = adam_step;
+    }
 }
 
 void Model::get_grad(const std::string& key, float* host, int64_t cap_bytes) {

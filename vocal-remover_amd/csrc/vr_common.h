@@ -126,6 +126,7 @@ struct ConvArgs {
     int pad_h, pad_w;
     int tiles_w, tiles_h, npt, nct;
     int dbg;                   // perf experiments only (VR_CONV_DBG): 1 = skip staging, 2 = skip MFMAs
+    int bf16;                  // 1: MFMA operands rounded to bf16 in registers (fp32 storage and accumulation), Winograd kernels only
     int tapmask;               // 0 = all taps; else bit t set = tap t of the 3x3 is used.  The data gradient of a
                                // stride-2 conv is four stride-1 convs over dz, one per output parity (ph, pw), with
                                // 1 / 2 / 2 / 4 live taps and outputs interleaved (dst.wshift, doubled row stride):
@@ -147,6 +148,7 @@ struct WgradArgs {
     long long part_stride;
     int P, tiles_w, tiles_h, npt, nchunks, nct;
     int dma;                   // 1: every source is a plain tensor -> the loader waves use LDS-DMA (no arithmetic)
+    int bf16;                  // 1: bf16 MFMA operands (wgrad_wino.hip, wgrad_gemm.hip)
     int allow_wino;            // 1: 3x3 stride-1 layers with plain inputs may take the Winograd F(3x3,2x2) kernel (wgrad_wino.hip)
 };
 double launch_wgrad(const WgradArgs& a, const ConvShape& s, float* grad_out, int accumulate, hipStream_t st);

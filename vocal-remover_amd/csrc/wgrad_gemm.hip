@@ -108,8 +108,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_gemm_kernel(const WgradArgs a, i
         for (int q = 0; q < KC / 8; ++q) {
             const f32x4v av = *reinterpret_cast<const f32x4v*>(st + a_off + 32 * q);
             const f32x4v bv = *reinterpret_cast<const f32x4v*>(st + b_off + 32 * q);
+            if (a.bf16) {
+                acc = mfma_bf16(pack_bf16x4(av[0], av[1], av[2], av[3]), pack_bf16x4(bv[0], bv[1], bv[2], bv[3]), acc);
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                   // every wave is done reading this stage

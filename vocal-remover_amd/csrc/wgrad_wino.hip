@@ -210,7 +210,31 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const WgradArgs a) {
     const float* Vb = Vs + (2 * wave) * CB * KP + l31 * KP + khalf;   // + fi*CB*KP + ni*32*KP + 2*s
     for (int pt = t_begin; pt < t_end; ++pt) {
         if (pt + 1 < t_end) issue_chunk(pt + 1);       // the raw buffers were last read by this wave's own transform
-        if (!(a.in.dbg & 2)) {
+        if (a.bf16) {
+            // bf16 operands: two v_mfma_f32_32x32x8_bf16 cover the chunk's 16 tiles of a frequency
+            const float* Ub = Us + (2 * wave) * MT * KP + l31 * KP + 4 * khalf;
+            const float* Vb2 = Vs + (2 * wave) * CB * KP + l31 * KP + 4 * khalf;
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+                for (int h8 = 0; h8 < 2; ++h8) {
+                    s16x4 A[WM], B[WN];
+#pragma unroll
+                    for (int mi = 0; mi < WM; ++mi) {
+                        const float* q = Ub + fi * MT * KP + mi * 32 * KP + 8 * h8;
+                        A[mi] = pack_bf16x4(q[0], q[1], q[2], q[3]);
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni) {
+                        const float* q = Vb2 + fi * CB * KP + ni * 32 * KP + 8 * h8;
+                        B[ni] = pack_bf16x4(q[0], q[1], q[2], q[3]);
+                    }
+#pragma unroll
+                    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < WN; ++ni) acc[fi][mi][ni] = mfma_bf16(A[mi], B[ni], acc[fi][mi][ni]);
+                }
+        } else if (!(a.in.dbg & 2)) {
             // 16 k-steps (2 frequencies x 8 tile pairs), operands of step s+1 read before the MFMAs of step s
             float av[WM], bv[WN];
 #pragma unroll

@@ -11,6 +11,8 @@ Drop-in at train.py:235-247: build the set with the same arguments plus the mode
 (X_batch, y_batch) already on the model's device, which is what train_epoch consumes (train.py:71-79).
 """
 import ctypes
+import os
+import random
 
 import numpy as np
 import torch
@@ -204,3 +206,67 @@ class DeviceLoader(object):
             if self.drop_last and len(idx) < self.batch_size:
                 break
             yield self.dataset.batch(idx)
+
+
+# ---- dataset preparation (lib/dataset.py:143-248): same file lists, cache layout and patch files as the reference ----
+def make_pair(mix_dir, inst_dir):
+    """lib/dataset.py:143-159."""
+    input_exts = ['.wav', '.m4a', '.mp3', '.mp4', '.flac']
+    X_list = sorted([os.path.join(mix_dir, fname) for fname in os.listdir(mix_dir) if os.path.splitext(fname)[1] in input_exts])
+    y_list = sorted([os.path.join(inst_dir, fname) for fname in os.listdir(inst_dir) if os.path.splitext(fname)[1] in input_exts])
+    return list(zip(X_list, y_list))
+
+
+def train_val_split(dataset_dir, split_mode, val_rate, val_filelist):
+    """lib/dataset.py:162-195 (uses the `random` module's stream exactly like the reference)."""
+    if split_mode == 'random':
+        filelist = make_pair(os.path.join(dataset_dir, 'mixtures'), os.path.join(dataset_dir, 'instruments'))
+        random.shuffle(filelist)
+        if len(val_filelist) == 0:
+            val_size = int(len(filelist) * val_rate)
+            train_filelist = filelist[:-val_size]
+            val_filelist = filelist[-val_size:]
+        else:
+            train_filelist = [pair for pair in filelist if list(pair) not in val_filelist]
+    elif split_mode == 'subdirs':
+        if len(val_filelist) != 0:
+            raise ValueError('`val_filelist` option is not available with `subdirs` mode')
+        train_filelist = make_pair(os.path.join(dataset_dir, 'training/mixtures'), os.path.join(dataset_dir, 'training/instruments'))
+        val_filelist = make_pair(os.path.join(dataset_dir, 'validation/mixtures'), os.path.join(dataset_dir, 'validation/instruments'))
+    return train_filelist, val_filelist
+
+
+def make_training_set(filelist, sr, hop_length, n_fft):
+    """lib/dataset.py:208-217: [[X_cache_path, y_cache_path, coef], ...]."""
+    from . import spec_utils
+    ret = []
+    for X_path, y_path in filelist:
+        X, y, X_cache_path, y_cache_path = spec_utils.cache_or_load(X_path, y_path, sr, hop_length, n_fft)
+        coef = np.max([np.abs(X).max(), np.abs(y).max()])
+        ret.append([X_cache_path, y_cache_path, coef])
+    return ret
+
+
+def make_validation_set(filelist, cropsize, sr, hop_length, n_fft, offset):
+    """lib/dataset.py:220-248: normalised, padded, overlapping cropsize-frame patches as .npz (keys X, y) in the
+    reference's directory `cs{}_sr{}_hl{}_nf{}_of{}` with the reference's file names."""
+    from . import spec_utils
+    patch_list = []
+    patch_dir = 'cs{}_sr{}_hl{}_nf{}_of{}'.format(cropsize, sr, hop_length, n_fft, offset)
+    os.makedirs(patch_dir, exist_ok=True)
+    for X_path, y_path in filelist:
+        basename = os.path.splitext(os.path.basename(X_path))[0]
+        X, y, _, _ = spec_utils.cache_or_load(X_path, y_path, sr, hop_length, n_fft)
+        coef = np.max([np.abs(X).max(), np.abs(y).max()])
+        X, y = X / coef, y / coef
+        l, r, roi_size = make_padding(X.shape[2], cropsize, offset)
+        X_pad = np.pad(X, ((0, 0), (0, 0), (l, r)), mode='constant')
+        y_pad = np.pad(y, ((0, 0), (0, 0), (l, r)), mode='constant')
+        len_dataset = int(np.ceil(X.shape[2] / roi_size))
+        for j in range(len_dataset):
+            outpath = os.path.join(patch_dir, '{}_p{}.npz'.format(basename, j))
+            start = j * roi_size
+            if not os.path.exists(outpath):
+                np.savez(outpath, X=X_pad[:, :, start:start + cropsize], y=y_pad[:, :, start:start + cropsize])
+            patch_list.append(outpath)
+    return patch_list

@@ -70,3 +70,50 @@ class Separator(object):
         native.check(native.lib().vr_separate_wave(h.h, native.np_ptr(wave), 0, L, self._flags(tta), int(self.batchsize),
                                                    int(self.cropsize), native.np_ptr(y), native.np_ptr(v), 0))
         return y, v
+
+
+def main(argv=None):
+    """inference.py main() (inference.py:107-185) with the same flags; decoding / resampling / WAV writing come from
+    vocal_remover_amd.audio (no librosa / soundfile), everything numeric from the library.  --output_image is the only
+    flag not carried over (cv2 image dump, SURVEY section 2: out of scope)."""
+    import argparse
+    import os
+
+    import torch
+
+    from . import audio, nets
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpu', '-g', type=int, default=0)
+    p.add_argument('--pretrained_model', '-P', type=str, required=True)
+    p.add_argument('--input', '-i', required=True)
+    p.add_argument('--sr', '-r', type=int, default=44100)
+    p.add_argument('--n_fft', '-f', type=int, default=2048)
+    p.add_argument('--hop_length', '-H', type=int, default=1024)
+    p.add_argument('--batchsize', '-B', type=int, default=4)
+    p.add_argument('--cropsize', '-c', type=int, default=256)
+    p.add_argument('--tta', '-t', action='store_true')
+    p.add_argument('--postprocess', '-p', action='store_true')
+    p.add_argument('--output_dir', '-o', type=str, default="")
+    args = p.parse_args(argv)
+
+    device = torch.device('cuda:{}'.format(max(args.gpu, 0)))
+    model = nets.CascadedNet(args.n_fft, args.hop_length, 32, 128)
+    model.load_state_dict(torch.load(args.pretrained_model, map_location='cpu'))
+    model.to(device)
+    X, sr = audio.load(args.input, sr=args.sr, mono=False, dtype=np.float32, res_type='kaiser_fast')
+    basename = os.path.splitext(os.path.basename(args.input))[0]
+    if X.ndim == 1:
+        X = np.asarray([X, X])                   # mono to stereo (inference.py:143-145)
+    sp = Separator(model=model, device=device, batchsize=args.batchsize, cropsize=args.cropsize, postprocess=args.postprocess)
+    y_wave, v_wave = sp.separate_wave(X, tta=args.tta)      # STFT -> separate -> iSTFT x2 in one device-resident call
+    output_dir = args.output_dir
+    if output_dir != "":
+        output_dir = output_dir.rstrip('/') + '/'
+        os.makedirs(output_dir, exist_ok=True)
+    audio.write('{}{}_Instruments.wav'.format(output_dir, basename), y_wave.T, sr)
+    audio.write('{}{}_Vocals.wav'.format(output_dir, basename), v_wave.T, sr)
+    return 0
+
+
+if __name__ == '__main__':
+    raise SystemExit(main())

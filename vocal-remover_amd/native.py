@@ -32,8 +32,13 @@ _SIGNATURES = {
                                         ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, ctypes.c_int]),
     'vr_train_step': (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, ctypes.POINTER(ctypes.c_float), c_f32p, ctypes.c_int]),
+    'vr_forward_train': (ctypes.c_int, [ctypes.c_void_p, c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_int]),
+    'vr_backward': (ctypes.c_int, [ctypes.c_void_p, c_f32p, ctypes.c_int]),
+    'vr_param_arena': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64)]),
     'vr_adam_step': (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_double] * 5),
     'vr_zero_grad': (ctypes.c_int, [ctypes.c_void_p]),
+    'vr_get_adam_state': (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_int64, c_i64p]),
+    'vr_set_adam_state': (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_int64, ctypes.c_int64]),
     'vr_get_grad': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_f32p, ctypes.c_int64]),
     'vr_set_dropout': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, c_f32p, ctypes.c_int]),
     'vr_grad_arena': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64)]),
@@ -51,6 +56,8 @@ _SIGNATURES = {
     'vr_debug_kernel': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_i64p, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
                                        ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int,
                                        ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]),
+    'vr_resample': (ctypes.c_int, [ctypes.c_int, c_f32p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, c_f32p, ctypes.c_int64]),
+    'vr_xcorr_argmax': (ctypes.c_int, [ctypes.c_int, c_f32p, ctypes.c_int64, c_f32p, ctypes.c_int64, c_i64p]),
     'vr_profile_begin': (ctypes.c_int, [ctypes.c_void_p]),
     'vr_profile_end': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
                                       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int),

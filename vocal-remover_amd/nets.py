@@ -94,6 +94,39 @@ def _init_tensor(shape, init):
     return torch.empty(shape).uniform_(-bound, bound)
 
 
+class _ForwardTrain(torch.autograd.Function):
+    """mask = model(X) with the graph kept inside the native handle (vr_forward_train); backward hands dLoss/dmask to
+    vr_backward, which ACCUMULATES the parameter gradients in the gradient arena (= flat.grad), like autograd would."""
+
+    @staticmethod
+    def forward(ctx, flat, x, model):
+        h = model._need_handle()
+        if x.dim() != 4 or x.shape[1] != 2 or x.shape[2] != model.output_bin:
+            raise ValueError('expected input [B, 2, %d, T], got %s' % (model.output_bin, tuple(x.shape)))
+        on_dev = x.is_cuda
+        xc = x.detach().to(torch.float32).contiguous()
+        mask = torch.empty_like(xc)
+        if on_dev:
+            torch.cuda.current_stream(x.device).synchronize()
+        native.check(native.lib().vr_forward_train(h.h, xc.data_ptr(), int(on_dev), int(xc.shape[0]), int(xc.shape[3]),
+                                                   mask.data_ptr(), int(on_dev)))
+        ctx.model = model
+        model._host_stale = True
+        return mask
+
+    @staticmethod
+    def backward(ctx, dmask):
+        model = ctx.model
+        h = model._need_handle()
+        on_dev = dmask.is_cuda
+        d = dmask.detach().to(torch.float32).contiguous()
+        if on_dev:
+            torch.cuda.current_stream(d.device).synchronize()
+        native.check(native.lib().vr_backward(h.h, d.data_ptr(), int(on_dev)))
+        model._flat_parameter()                     # (re-)attach .grad to the arena view
+        return None, None, None
+
+
 class CascadedNet(object):
 
     def __init__(self, n_fft, hop_length, nout=32, nout_lstm=128, is_complex=False):
@@ -205,7 +238,15 @@ class CascadedNet(object):
         return out
 
     def forward(self, x):
-        """CascadedNet.forward (lib/nets.py:82-117): mask [B,2,n_fft/2+1,T]."""
+        """CascadedNet.forward (lib/nets.py:82-117): mask [B,2,n_fft/2+1,T].
+
+        Under model.train() with autograd enabled (the reference's train_epoch, train.py:81) the returned mask is
+        differentiable: `loss.backward()` reaches the native backward pass through _ForwardTrain and the gradients
+        accumulate in the library's gradient arena = `.grad` of the flat parameter `parameters()` hands to the optimizer."""
+        if self.training and torch.is_grad_enabled() and self._handle is not None:
+            if not torch.is_tensor(x):
+                x = torch.as_tensor(x)
+            return _ForwardTrain.apply(self._flat_parameter(), x, self)
         return self._run(x, 0)
 
     __call__ = forward
@@ -219,15 +260,38 @@ class CascadedNet(object):
         return self._run(x, 2)
 
     # ---- training (train.py:77-96) ----------------------------------------------------------------------
-    def parameters(self):
-        """Stands in for nn.Module.parameters(): one reference to the native parameter arena, accepted
-        by vocal_remover_amd.train.Adam (the reference filters on .requires_grad, train.py:216)."""
-        from .train import _ParamRef
-        return [_ParamRef(self)]
+    def _arena_tensor(self, fn):
+        import ctypes
+        h = self._need_handle()
+        ptr, n = ctypes.c_void_p(), ctypes.c_int64()
+        native.check(fn(h.h, ctypes.byref(ptr), ctypes.byref(n)))
 
-    def zero_grad(self):
+        class _Arr(object):
+            __cuda_array_interface__ = {'shape': (int(n.value),), 'typestr': '<f4', 'data': (int(ptr.value), False), 'version': 2}
+        return torch.as_tensor(_Arr(), device=torch.device('cuda', h.device))
+
+    def _flat_parameter(self):
+        """ONE torch Parameter = a zero-copy view of the library's flat fp32 parameter arena (kernel layouts, padding
+        included), `.grad` = a view of the gradient arena.  Element-wise optimizers (torch.optim.Adam of train.py:215,
+        or vocal_remover_amd.train.Adam's fused kernel) do not care about the layout; padding has zero gradient."""
+        key = id(self._handle)
+        if getattr(self, '_flat_key', None) != key:
+            flat = torch.nn.Parameter(self._arena_tensor(native.lib().vr_param_arena), requires_grad=True)
+            flat._vr_model = self
+            self._flat, self._flat_grad, self._flat_key = flat, self._arena_tensor(native.lib().vr_grad_arena), key
+        if self._flat.grad is None or self._flat.grad.data_ptr() != self._flat_grad.data_ptr():
+            self._flat.grad = self._flat_grad
+        return self._flat
+
+    def parameters(self):
+        """Stands in for nn.Module.parameters() (train.py:216 filters on .requires_grad): the flat parameter."""
+        return [self._flat_parameter()]
+
+    def zero_grad(self, set_to_none=False):
         if self._handle is not None:
             native.check(native.lib().vr_zero_grad(self._handle.h))
+            if getattr(self, '_flat', None) is not None:
+                self._flat.grad = self._flat_grad                     # stays the arena view (never None)
 
     def train_step(self, X, y, accumulation_steps=1, return_mask=False):
         """mask = model(X); loss = L1Loss()(mask * X, y); (loss / accumulation_steps).backward()

@@ -17,30 +17,22 @@ import torch
 from . import native
 
 
-class _ParamRef(object):
-    """What CascadedNet.parameters() yields: a handle to the native parameter arena."""
-    requires_grad = True
-
-    def __init__(self, model):
-        self.model = model
-
-
 class Adam(torch.optim.Optimizer):
     """torch.optim.Adam(params, lr) with the reference's defaults (train.py:215-218), executed by the fused
     vr_adam_step over the library's flat parameter / gradient / moment arenas.  It IS a torch Optimizer (one
     param group, a placeholder tensor), so torch.optim.lr_scheduler.ReduceLROnPlateau (train.py:220-227) drives
-    `param_groups[0]['lr']` exactly as in the reference."""
+    `param_groups[0]['lr']` exactly as in the reference.  (torch.optim.Adam itself also works on model.parameters():
+    the flat parameter is a zero-copy view of the arena -- that is how the reference's train.py runs unmodified.)"""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
         if weight_decay != 0:
             raise NotImplementedError('the reference trains with weight_decay=0 (train.py:215-218)')
-        refs = [p for p in params if isinstance(p, _ParamRef)]
+        refs = [p for p in params if getattr(p, '_vr_model', None) is not None]
         if not refs:
             raise ValueError('pass model.parameters() of a vocal_remover_amd CascadedNet')
-        self.model = refs[0].model
+        self.model = refs[0]._vr_model
         self.grad_scale = 1.0
-        self._placeholder = torch.zeros(1, requires_grad=True)
-        super().__init__([self._placeholder], dict(lr=lr, betas=betas, eps=eps))
+        super().__init__(refs[:1], dict(lr=lr, betas=betas, eps=eps))
         self.model.set_option('adam_reset', 1)      # a new optimizer starts without moments, like torch.optim.Adam
 
     def step(self, closure=None):
@@ -207,3 +199,74 @@ def validate_epoch(dataloader, model, device):
         loss = model.validate_step(X_batch, y_batch)
         sum_loss += loss * len(X_batch)
     return sum_loss / len(dataloader.dataset)
+
+
+# ---- the epoch loop of train.py main() (train.py:272-294) + what the reference lacks: a resumable checkpoint ----------
+def save_checkpoint(path, model, optimizer, scheduler=None, epoch=0, best_loss=None, log=None):
+    """Model state_dict (the reference's 689 keys) + Adam moments / step + scheduler state + loop position."""
+    h = model._need_handle()
+    import ctypes
+    n = model._arena_tensor(native.lib().vr_grad_arena).numel()
+    state = {'model': model.state_dict(), 'epoch': int(epoch), 'best_loss': best_loss, 'log': list(log or []),
+             'lr': optimizer.param_groups[0]['lr']}
+    if isinstance(optimizer, Adam):
+        m = torch.empty(n, dtype=torch.float32)
+        v = torch.empty(n, dtype=torch.float32)
+        step = ctypes.c_int64()
+        native.check(native.lib().vr_get_adam_state(h.h, m.data_ptr(), v.data_ptr(), n, ctypes.byref(step)))
+        state['adam'] = {'exp_avg': m, 'exp_avg_sq': v, 'step': int(step.value)}
+    else:
+        state['optimizer'] = optimizer.state_dict()
+    if scheduler is not None:
+        state['scheduler'] = scheduler.state_dict()
+    torch.save(state, path)
+
+
+def load_checkpoint(path, model, optimizer, scheduler=None):
+    """Inverse of save_checkpoint; returns (next_epoch, best_loss, log)."""
+    state = torch.load(path, map_location='cpu')
+    model.load_state_dict(state['model'])
+    h = model._need_handle()
+    if 'adam' in state and isinstance(optimizer, Adam):
+        a = state['adam']
+        m, v = a['exp_avg'].contiguous(), a['exp_avg_sq'].contiguous()
+        native.check(native.lib().vr_set_adam_state(h.h, m.data_ptr(), v.data_ptr(), m.numel(), int(a['step'])))
+    elif 'optimizer' in state:
+        optimizer.load_state_dict(state['optimizer'])
+    optimizer.param_groups[0]['lr'] = state.get('lr', optimizer.param_groups[0]['lr'])
+    if scheduler is not None and 'scheduler' in state:
+        scheduler.load_state_dict(state['scheduler'])
+    return state['epoch'] + 1, state['best_loss'], state['log']
+
+
+def fit(model, device, train_dataloader, val_dataloader, optimizer, scheduler, epochs, accumulation_steps=1,
+        model_dir='models', log_path=None, checkpoint_path=None, logger=None, start_epoch=0, best_loss=None, log=None):
+    """train.py:272-294: per epoch train_epoch, validate_epoch, scheduler.step(val_loss), save the model on a new best
+    validation loss as `models/model_iter{epoch}.pth` (state_dict, loadable by the reference), append [train, val] to
+    the loss json.  Additionally writes a resumable checkpoint (optimizer moments included) when asked."""
+    import json
+    import numpy as np
+    log = list(log or [])
+    best_loss = np.inf if best_loss is None else best_loss
+    for epoch in range(start_epoch, epochs):
+        if logger:
+            logger.info('# epoch {}'.format(epoch))
+        train_loss = train_epoch(train_dataloader, model, device, optimizer, accumulation_steps)
+        val_loss = validate_epoch(val_dataloader, model, device)
+        if logger:
+            logger.info('  * training loss = {:.6f}, validation loss = {:.6f}'.format(train_loss, val_loss))
+        scheduler.step(val_loss)
+        if val_loss < best_loss:
+            best_loss = val_loss
+            if logger:
+                logger.info('  * best validation loss')
+            import os
+            os.makedirs(model_dir, exist_ok=True)
+            torch.save(model.state_dict(), os.path.join(model_dir, 'model_iter{}.pth'.format(epoch)))
+        log.append([train_loss, val_loss])
+        if log_path:
+            with open(log_path, 'w', encoding='utf8') as f:
+                json.dump(log, f, ensure_ascii=False)
+        if checkpoint_path:
+            save_checkpoint(checkpoint_path, model, optimizer, scheduler, epoch, best_loss, log)
+    return log, best_loss
