@@ -150,6 +150,7 @@ def main():
     ap.add_argument('--batchsize', type=int, default=0, help='crops per device batch (0 = all crops of a pass)')
     ap.add_argument('--train-batch', type=int, default=16)
     ap.add_argument('--wire', choices=['fp32', 'bf16'], default='fp32', help='gradient bucket format on xGMI (N > 1)')
+    ap.add_argument('--bf16', action='store_true', help='--mode train: configs[4] arithmetic (bf16 MFMA operands, bf16 bucket)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
     if args.tta:
@@ -246,10 +247,12 @@ def main():
                'frames_per_step_per_gpu': T}
         return res, step
 
-    def run_train():
+    def run_train(bf16=False):
         from vocal_remover_amd import train as vtrain
+        net.set_option('mfma_bf16', 1 if bf16 else 0)
+        wire = 'bf16' if (bf16 and world > 1) else args.wire
         trainer = vtrain.Trainer(net, lr=1e-3, world_size=world, rank=rank, backend='rccl' if world > 1 else 'none',
-                                 wire=args.wire if world > 1 else 'fp32')
+                                 wire=wire if world > 1 else 'fp32')
         g = torch.Generator().manual_seed(rank)
         B = args.train_batch
         X = torch.rand((B, 2, N_FFT // 2 + 1, CROP), generator=g)
@@ -259,8 +262,10 @@ def main():
         dt = timed(step, args.steps, args.warmup)
         res = {'frames_per_sec': world * B * CROP * args.steps / dt, 'ms_per_step': dt / args.steps * 1e3,
                'global_batch': world * B, 'frames_per_step_per_gpu': B * CROP,
-               'workload': 'configs[3]: train.py step, batch %d x [2,1025,256] per GPU, fwd + L1 + bwd%s + Adam; '
-                           'Dropout2d live (library RNG)' % (B, ' + RCCL all-reduce (%s bucket)' % args.wire if world > 1 else ''),
+               'workload': 'configs[%d]: train.py step, batch %d x [2,1025,256] per GPU, fwd + L1 + bwd%s + Adam; '
+                           'Dropout2d live (library RNG)' % (4 if bf16 else 3, B, ' + RCCL all-reduce (%s bucket)' % wire if world > 1 else ''),
+               'dtype': 'bf16 MFMA operands (Winograd forward / data-gradient / weight-gradient convs, 1x1 weight-gradient GEMM), '
+                        'fp32 accumulation, storage, master weights and Adam; remaining convs fp32' if bf16 else 'f32',
                'parallelism': 'dp%d (one RCCL all-reduce of the flat 14.74 M-element gradient bucket per step)' % world}
         return res, step
 
@@ -276,7 +281,7 @@ def main():
         parallelism = 'replicas x%d (songs shard, no collective)' % world
         roof = roofline(step, CONV_FAMILY_INFER, 'r02_infer_pmc.json' if primary_mode == 'infer' else 'r02_tta_pmc.json')
     else:
-        res, step = run_train()
+        res, step = run_train(args.bf16)
         workload, metric, parallelism = res['workload'], 'spectrogram-frames/sec (train-step, CascadedNet n_fft=2048)', res['parallelism']
         roof = roofline(step, CONV_FAMILY_TRAIN, 'r02_train_pmc.json')
         net.eval()
@@ -284,7 +289,7 @@ def main():
         out = {
             'metric': metric, 'value': res['frames_per_sec'], 'unit': 'spectrogram-frames/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': res['ms_per_step'],
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': res.get('dtype', 'f32'),
             'data': 'synthetic (seeded noise + sines; seeded random weights, no baseline.pth exists)',
             'config': {'workload': workload, 'n_fft': N_FFT, 'hop': HOP, 'cropsize': CROP,
                        'frames_per_step_per_gpu': res['frames_per_step_per_gpu'], 'parallelism': parallelism,
@@ -305,6 +310,8 @@ def main():
         tta_roof = roofline(tta_step, CONV_FAMILY_INFER, 'r02_tta_pmc.json')
         train_res, train_step_fn = run_train()
         train_roof = roofline(train_step_fn, CONV_FAMILY_TRAIN, 'r02_train_pmc.json')
+        bf_res, _ = run_train(True)
+        net.set_option('mfma_bf16', 0)
         net.eval()
         if rank == 0:
             out['config']['pcie_inclusive_frames_per_sec'] = extra.get('pcie_inclusive_frames_per_sec')
@@ -316,6 +323,10 @@ def main():
                             'ms_per_step': train_res['ms_per_step'], 'steps': args.steps, 'warmup': args.warmup,
                             'global_batch': train_res['global_batch'], 'workload': train_res['workload'],
                             'parallelism': train_res['parallelism'], 'dtype': 'f32', 'roofline': train_roof}
+            out['train_bf16'] = {'metric': 'spectrogram-frames/sec (train-step, configs[4] arithmetic on %d GPU%s)' % (world, 's' if world > 1 else ''),
+                                 'value': bf_res['frames_per_sec'], 'ms_per_step': bf_res['ms_per_step'], 'steps': args.steps,
+                                 'warmup': args.warmup, 'global_batch': bf_res['global_batch'], 'workload': bf_res['workload'],
+                                 'parallelism': bf_res['parallelism'], 'dtype': bf_res['dtype']}
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

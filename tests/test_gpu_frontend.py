@@ -79,7 +79,7 @@ def test_reference_train_epoch_statements_run_through_the_autograd_shim(vr):
     assert all(float(v.abs().max()) == 0.0 for v in b.grads(keys={'out.weight'}).values())
     # a forward in between frees the graph: backward must fail loudly, not corrupt
     pred = b(Xd[:2])
-    b.eval(); b.predict_mask(Xd[:2]); b.train()
+    b.eval(); b(Xd[:2]); b.train()
     with pytest.raises(ValueError):
         (pred.sum()).backward()
 

@@ -16,13 +16,17 @@ __device__ __forceinline__ float act_apply(float v, float slope) { return v > 0.
 // registers right before the MFMA, products accumulate in fp32.  v_mfma_f32_32x32x8_bf16: lane (row/col = lane & 31,
 // kgroup = lane >> 5) supplies the 4 operands k = 4*kgroup .. 4*kgroup+3; 8 passes for 4x the k of the fp32 instruction.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float vr_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 vr_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 vr_bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ s16x4 pack_bf16x4(float a, float b, float c, float d) {
-    unsigned lo, hi;
-    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
-    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(c), "v"(d));
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    u32x2 u; u[0] = lo; u[1] = hi;
-    return __builtin_bit_cast(s16x4, u);
+    // (compiler builtin, not inline asm: the hazard recogniser must see the VALU write in front of the MFMA read)
+    vr_f32x2 lo, hi;
+    lo[0] = a; lo[1] = b; hi[0] = c; hi[1] = d;
+    const vr_bf16x2 l = __builtin_convertvector(lo, vr_bf16x2), h = __builtin_convertvector(hi, vr_bf16x2);
+    vr_bf16x4 v;
+    v[0] = l[0]; v[1] = l[1]; v[2] = h[0]; v[3] = h[1];
+    return __builtin_bit_cast(s16x4, v);
 }
 __device__ __forceinline__ f32x16 mfma_bf16(s16x4 a, s16x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, b, c, 0, 0, 0);

@@ -48,7 +48,8 @@ struct WinoCfg {
     static_assert(16 * 32 * MP + 2 * MT <= LDS_FLOATS && LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <int MT>
+template <int MT, bool BF>      // BF: bf16 operands on the matrix pipe (ConvArgs::bf16), its own instantiation: a run-time branch
+                                // around the two MFMA loops costs the fp32 kernel 60 spilled registers
 __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
     using Cfg = WinoCfg<MT>;
     constexpr int TH = Cfg::TH, TW = Cfg::TW, CK = Cfg::CK, NT = Cfg::NT, TWq = Cfg::TWq, CSX = Cfg::CSX, XS0 = Cfg::XS0,
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
         if (k + 1 < nchunk) issue_chunk(k + 1);
         const float* Ws = WsB + (k & 1) * Cfg::WS + (2 * wave) * CK * MT + aoff;
         const float* Vs = VsB + (k % Cfg::NVB) * Cfg::VS + (2 * wave) * CK * NT + boff;
-        if (a.bf16) {
+        if constexpr (BF) {
             // bf16 operands: one v_mfma_f32_32x32x8_bf16 covers the chunk's 8 input channels of a frequency
             const float* Wb = WsB + (k & 1) * Cfg::WS + (2 * wave) * CK * MT + (4 * khalf) * MT + l31;
             const float* Vb = VsB + (k % Cfg::NVB) * Cfg::VS + (2 * wave) * CK * NT + (4 * khalf) * NT + l31;
@@ -360,10 +361,10 @@ void launch_wino_weights(const float* w, float* u, int Cin, int CoutPad, hipStre
     VR_HIP(hipGetLastError());
 }
 
-template <int MT>
+template <int MT, bool BF>
 static void wino_launch(const ConvArgs& a, hipStream_t st) {
     using Cfg = WinoCfg<MT>;
-    auto kern = conv_wino_kernel<MT>;
+    auto kern = conv_wino_kernel<MT, BF>;
     static std::atomic<unsigned long long> attr_done{0};          // per device (bit = device index)
     ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
     const int groups = (a.npt + 7) / 8;
@@ -406,8 +407,11 @@ void wino_fill_tiling(ConvArgs& a, int MT) {
 }
 
 void wino_launch_conv(const ConvArgs& a, int MT, hipStream_t st) {
-    if (MT == 64) wino_launch<64>(a, st);
-    else wino_launch<32>(a, st);
+    if (a.bf16) {
+        if (MT == 64) wino_launch<64, true>(a, st); else wino_launch<32, true>(a, st);
+    } else {
+        if (MT == 64) wino_launch<64, false>(a, st); else wino_launch<32, false>(a, st);
+    }
 }
 
 }  // namespace vr

@@ -25,6 +25,7 @@ struct WgGemmCfg {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+template <bool BF>
 __global__ __launch_bounds__(512, 2) void wgrad_gemm_kernel(const WgradArgs a, int chunks_per_img, long long img_pixels) {
     using Cfg = WgGemmCfg;
     constexpr int MT = Cfg::MT, CB = Cfg::CB, KC = Cfg::KC, RP = Cfg::RP, D = Cfg::D, NI = Cfg::NI;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_gemm_kernel(const WgradArgs a, i
         for (int q = 0; q < KC / 8; ++q) {
             const f32x4v av = *reinterpret_cast<const f32x4v*>(st + a_off + 32 * q);
             const f32x4v bv = *reinterpret_cast<const f32x4v*>(st + b_off + 32 * q);
-            if (a.bf16) {
+            if constexpr (BF) {
                 acc = mfma_bf16(pack_bf16x4(av[0], av[1], av[2], av[3]), pack_bf16x4(bv[0], bv[1], bv[2], bv[3]), acc);
             } else {
 #pragma unroll
@@ -171,11 +172,17 @@ void wgrad_gemm_plan(WgradArgs& a) {
 }
 
 void wgrad_gemm_launch(const WgradArgs& a, hipStream_t st) {
-    static std::atomic<unsigned long long> attr_done{0};          // per device (bit = device index)
-    ensure_lds_attr(attr_done, reinterpret_cast<const void*>(wgrad_gemm_kernel), WgGemmCfg::LDS_BYTES);
+    static std::atomic<unsigned long long> attr_done{0}, attr_done_bf{0};          // per device (bit = device index)
     const int grid = ((a.P + 7) / 8) * 8 * a.nchunks * a.nct;
-    hipLaunchKernelGGL(wgrad_gemm_kernel, dim3(grid), dim3(512), WgGemmCfg::LDS_BYTES, st, a, a.tiles_w,
-                       (long long)a.in.Hout * a.in.Wout);
+    if (a.bf16) {
+        ensure_lds_attr(attr_done_bf, reinterpret_cast<const void*>(wgrad_gemm_kernel<true>), WgGemmCfg::LDS_BYTES);
+        hipLaunchKernelGGL(wgrad_gemm_kernel<true>, dim3(grid), dim3(512), WgGemmCfg::LDS_BYTES, st, a, a.tiles_w,
+                           (long long)a.in.Hout * a.in.Wout);
+    } else {
+        ensure_lds_attr(attr_done, reinterpret_cast<const void*>(wgrad_gemm_kernel<false>), WgGemmCfg::LDS_BYTES);
+        hipLaunchKernelGGL(wgrad_gemm_kernel<false>, dim3(grid), dim3(512), WgGemmCfg::LDS_BYTES, st, a, a.tiles_w,
+                           (long long)a.in.Hout * a.in.Wout);
+    }
     VR_HIP(hipGetLastError());
 }
 

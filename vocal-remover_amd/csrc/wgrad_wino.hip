@@ -45,7 +45,7 @@ struct WwCfg {
     static_assert(16 * 32 * MP <= LDS_FLOATS && LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <int CB, int MT>
+template <int CB, int MT, bool BF>
 __global__ __launch_bounds__(512) void wgrad_wino_kernel(const WgradArgs a) {
     using Cfg = WwCfg<CB, MT>;
     constexpr int TH = Cfg::TH, TW = Cfg::TW, TWq = Cfg::TWq, CSX = Cfg::CSX, CSZ = Cfg::CSZ, KP = Cfg::KP, XS0 = Cfg::XS0,
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const WgradArgs a) {
     const float* Vb = Vs + (2 * wave) * CB * KP + l31 * KP + khalf;   // + fi*CB*KP + ni*32*KP + 2*s
     for (int pt = t_begin; pt < t_end; ++pt) {
         if (pt + 1 < t_end) issue_chunk(pt + 1);       // the raw buffers were last read by this wave's own transform
-        if (a.bf16) {
+        if constexpr (BF) {
             // bf16 operands: two v_mfma_f32_32x32x8_bf16 cover the chunk's 16 tiles of a frequency
             const float* Ub = Us + (2 * wave) * MT * KP + l31 * KP + 4 * khalf;
             const float* Vb2 = Vs + (2 * wave) * CB * KP + l31 * KP + 4 * khalf;
@@ -363,10 +363,10 @@ void wgrad_wino_plan(WgradArgs& a, int CB, int MT) {
     a.P = (int)P;
 }
 
-template <int CB, int MT>
+template <int CB, int MT, bool BF>
 static void ww_launch(const WgradArgs& a, hipStream_t st) {
     using Cfg = WwCfg<CB, MT>;
-    auto kern = wgrad_wino_kernel<CB, MT>;
+    auto kern = wgrad_wino_kernel<CB, MT, BF>;
     static std::atomic<unsigned long long> attr_done{0};          // per device (bit = device index)
     ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
     const int grid = ((a.P + 7) / 8) * 8 * a.nchunks * a.nct;
@@ -378,9 +378,15 @@ void wgrad_wino_launch(const WgradArgs& a_in, int CB, int MT, hipStream_t st) {
     WgradArgs a = a_in;
     static const int dbg = [] { const char* e = getenv("VR_WW_DBG"); return e ? atoi(e) : 0; }();   // ablations (perf only)
     a.in.dbg = dbg;
-    if (CB == 32 && MT == 64) ww_launch<32, 64>(a, st);
-    else if (CB == 64 && MT == 32) ww_launch<64, 32>(a, st);
-    else ww_launch<32, 32>(a, st);
+    if (a.bf16) {
+        if (CB == 32 && MT == 64) ww_launch<32, 64, true>(a, st);
+        else if (CB == 64 && MT == 32) ww_launch<64, 32, true>(a, st);
+        else ww_launch<32, 32, true>(a, st);
+    } else {
+        if (CB == 32 && MT == 64) ww_launch<32, 64, false>(a, st);
+        else if (CB == 64 && MT == 32) ww_launch<64, 32, false>(a, st);
+        else ww_launch<32, 32, false>(a, st);
+    }
 }
 
 }  // namespace vr
