@@ -114,13 +114,18 @@ struct FFTPlan { int n_fft; int log2n; float2* twiddle; float* window; };
 void launch_stft(const FFTPlan& pl, const float* wave, long long L, int hop, int T, float2* spec, hipStream_t st);
 // spec [2][bins][T] -> frames scratch [2][T][n_fft] -> wave [2][hop*(T-1)]
 void launch_istft(const FFTPlan& pl, const float2* spec, int hop, int T, float* frames, float* wave, hipStream_t st);
+// Fused form for hop == n_fft/2: wave = istft(m * spec) (which 0) or istft(spec - m * spec) (which 1); mask_a null = plain
+// istft.  No frame buffer, no materialised y / v spectrograms (inference.py:26-40 + lib/spec_utils.py:157-165 in one pass).
+bool istft_masked_available(const FFTPlan& pl, int hop);
+void launch_istft_masked(const FFTPlan& pl, const float2* spec, int hop, int T, const float* mask_a, int Wa, const float* mask_b,
+                         int Wb, int shift, const float* wgt, int which, float* wave, hipStream_t st);
 // mag_pad [2][bins][Wpad] (pre-zeroed) <- |spec| at column pad_l + t; maxima into stats:
-// stats[0] = max |X| as float bits (uint), stats[2..3] = 64-bit lexicographic complex max key
+// per-row partial maxima into stats (16 B header + 2 x bins rows of (max |X| bits, 64-bit lexicographic complex key))
 void launch_mag_pad(const float2* spec, int bins, int T, float* mag_pad, int Wpad, int pad_l,
                     unsigned* stats, hipStream_t st);
 void launch_stats_init(unsigned* stats, hipStream_t st);
 // aff[0..3] = (1/coef, 0, 1/coef, 0), coef = max|X| (mode 0) or |lexicographic max| (mode 1)
-void launch_coef_affine(const unsigned* stats, int mode, float* aff, hipStream_t st);
+void launch_coef_affine(const unsigned* stats, int rows, int mode, float* aff, hipStream_t st);   // rows = 2 * bins partials
 // y = m*X, v = (1-m)*X with m = mask_a[.., t] (tta=0) or 0.5*(mask_a[.., t] + mask_b[.., t + shift])
 // wgt [T] (or null): per-frame merge_artifacts weight, m += wgt[t] * (1 - m)
 void launch_apply_mask(const float2* spec, int bins, int T, const float* mask_a, int Wa,

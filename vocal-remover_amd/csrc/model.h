@@ -126,7 +126,8 @@ public:
     void istft_api(const float* spec, bool on_dev, int T, float* wave, bool wave_on_dev);
     // spec [2,bins,T] complex64 -> y_spec, v_spec (same shape)
     void separate_api(const float* spec, bool on_dev, int T, int tta, int batchsize, int cropsize,
-                      float* y_spec, float* v_spec, bool out_on_dev, bool io_reserved = false);
+                      float* y_spec, float* v_spec, bool out_on_dev, bool io_reserved = false,
+                      float* y_wave_d = nullptr, float* v_wave_d = nullptr);
     // wave [2,L] -> y_wave, v_wave [2, hop*(T-1)]: whole inference.py pipeline, device resident
     void separate_wave_api(const float* wave, bool on_dev, long long L, int tta, int batchsize, int cropsize,
                            float* y_wave, float* v_wave, bool out_on_dev);

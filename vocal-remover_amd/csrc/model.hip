@@ -1104,11 +1104,11 @@ static size_t separate_scratch_floats(int bins, int T, int cropsize, int offset,
     int l, r, roi;
     make_padding(T, cropsize, offset, l, r, roi);
     const size_t Wpad2 = (size_t)T + l + r + roi;
-    return 2 * (size_t)2 * bins * Wpad2 * (tta ? 2 : 1) + 2 * (size_t)T + 4096;
+    return 2 * (size_t)2 * bins * Wpad2 * (tta ? 2 : 1) + 2 * (size_t)T + (size_t)8 * bins + 4096;
 }
 
 void Model::separate_api(const float* spec, bool on_dev, int T, int tta, int batchsize, int cropsize, float* y_spec,
-                         float* v_spec, bool out_on_dev, bool io_reserved) {
+                         float* v_spec, bool out_on_dev, bool io_reserved, float* y_wave_d, float* v_wave_d) {
     DeviceGuard dev_guard(device);
     const bool post = (tta & 2) != 0;       // flags: bit 0 = --tta, bit 1 = --postprocess
     tta &= 1;
@@ -1135,7 +1135,7 @@ void Model::separate_api(const float* spec, bool on_dev, int T, int tta, int bat
     }
     float* yd = out_on_dev ? y_spec : io.allocf(spec_f);
     float* vd = out_on_dev ? v_spec : io.allocf(spec_f);
-    unsigned* stats = static_cast<unsigned*>(io.alloc(64));
+    unsigned* stats = static_cast<unsigned*>(io.alloc(16 + (size_t)2 * bins * 16));
     float* in_aff = io.allocf(16);
     const int npass = tta ? 2 : 1;
     float* mask[2] = {nullptr, nullptr};
@@ -1156,9 +1156,8 @@ void Model::separate_api(const float* spec, bool on_dev, int T, int tta, int bat
         Wm[ps] = patches * roi;
         mask[ps] = io.allocf((size_t)2 * bins * Wm[ps]);
         VR_HIP(hipMemsetAsync(mag, 0, (size_t)2 * bins * Wpad * sizeof(float), stream));
-        launch_stats_init(stats, stream);
         launch_mag_pad(reinterpret_cast<const float2*>(sd), bins, T, mag, Wpad, pl, stats, stream);
-        launch_coef_affine(stats, tta ? 1 : 0, in_aff, stream);
+        launch_coef_affine(stats, 2 * bins, tta ? 1 : 0, in_aff, stream);
         {   // X_mag / coef once, so that the first conv of every BaseNet reads a plain tensor (LDS-DMA path)
             Tensor m;
             m.p = mag; m.N = 1; m.C = 2; m.H = bins; m.W = Wpad;
@@ -1228,6 +1227,15 @@ void Model::separate_api(const float* spec, bool on_dev, int T, int tta, int bat
         VR_HIP(hipStreamSynchronize(stream));
         wgt = wgt_d;
     }
+    if (y_wave_d && v_wave_d) {
+        // wave-level caller: mask application, inverse FFT, window and overlap-add in one pass per stem -- the y / v
+        // spectrograms (inference.py:32-38) are never materialised
+        for (int which = 0; which < 2; ++which)
+            launch_istft_masked(plan, reinterpret_cast<const float2*>(sd), hop, T, mask[0], Wm[0], tta ? mask[1] : nullptr, Wm[1],
+                                roi / 2, wgt, which, which ? v_wave_d : y_wave_d, stream);
+        VR_HIP(hipStreamSynchronize(stream));
+        return;
+    }
     launch_apply_mask(reinterpret_cast<const float2*>(sd), bins, T, mask[0], Wm[0], tta ? mask[1] : nullptr, Wm[1], roi / 2,
                       wgt, reinterpret_cast<float2*>(yd), reinterpret_cast<float2*>(vd), stream);
     if (!out_on_dev) {
@@ -1262,9 +1270,13 @@ void Model::separate_wave_api(const float* wave, bool on_dev, long long L, int t
     float* yw = out_on_dev ? y_wave : io.allocf(out_f + 4);
     float* vw = out_on_dev ? v_wave : io.allocf(out_f + 4);
     launch_stft(plan, wd, L, hop, T, reinterpret_cast<float2*>(spec), stream);
-    separate_api(spec, true, T, tta, batchsize, cropsize, ys, vs, true, /*io_reserved=*/true);
-    launch_istft(plan, reinterpret_cast<const float2*>(ys), hop, T, frames, yw, stream);
-    launch_istft(plan, reinterpret_cast<const float2*>(vs), hop, T, frames, vw, stream);
+    if (istft_masked_available(plan, hop) && out_f) {
+        separate_api(spec, true, T, tta, batchsize, cropsize, ys, vs, true, /*io_reserved=*/true, yw, vw);
+    } else {
+        separate_api(spec, true, T, tta, batchsize, cropsize, ys, vs, true, /*io_reserved=*/true);
+        launch_istft(plan, reinterpret_cast<const float2*>(ys), hop, T, frames, yw, stream);
+        launch_istft(plan, reinterpret_cast<const float2*>(vs), hop, T, frames, vw, stream);
+    }
     if (!out_on_dev && out_f) {
         VR_HIP(hipMemcpyAsync(y_wave, yw, out_f * sizeof(float), hipMemcpyDeviceToHost, stream));
         VR_HIP(hipMemcpyAsync(v_wave, vw, out_f * sizeof(float), hipMemcpyDeviceToHost, stream));
