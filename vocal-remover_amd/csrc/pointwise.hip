@@ -1,6 +1,8 @@
 // HBM-bound kernels around the conv stack: thin 1x1 convs (Cout 1/2), the mask head, frequency
 // average pool, BatchNorm statistics bookkeeping.  All are streaming kernels: 16-byte loads along
 // the contiguous time axis, one pass over the data, nothing re-read.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace vr {
@@ -280,10 +282,72 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(Tensor x, float* __rest
     else reinterpret_cast<float2*>(out)[gid] = make_float2(o[0], o[1]);
 }
 
+// Row-tiled form (even source widths): a thread group = one output row of one (n, c) plane, so the row weights, the two
+// source rows, the affine and the dropout factor are wave-uniform and no per-element division is left; a thread makes four
+// consecutive output columns (one 16-byte store) from at most four consecutive source columns per row.
+__global__ __launch_bounds__(256) void upsample2x_rows_kernel(Tensor x, float* __restrict__ out, float rh, float rw, int qp_log2,
+                                                              long long nrows) {
+    const int W2 = 2 * x.W, H2 = 2 * x.H;
+    // 2^qp_log2 threads per output row (>= quads of 4 columns, capped at 256), 256 >> qp_log2 rows per workgroup
+    const int q = (qp_log2 >= 8 ? blockIdx.y * 256 : 0) + (threadIdx.x & ((1 << qp_log2) - 1));
+    const long long row = (long long)blockIdx.x * (256 >> qp_log2) + (threadIdx.x >> qp_log2);
+    if (4 * q >= W2 || row >= nrows) return;
+    const int hi = (int)(row % H2);
+    const int pc = (int)(row / H2);                            // n * C + c
+    const int c = pc % x.C, n = pc / x.C;
+    const float h1r = rh * (float)hi;
+    const int h1 = (int)h1r;
+    const int h1p = (h1 < x.H - 1) ? 1 : 0;
+    const float h1l = h1r - (float)h1, h0l = 1.f - h1l;
+    const float* r0 = x.p + (long long)n * x.sN + (long long)c * x.sC + (long long)h1 * x.sH;
+    const float* r1 = r0 + (long long)h1p * x.sH;
+    float sc0, sh0, sc1, sh1;
+    load_aff(x, h1, c, sc0, sh0);
+    load_aff(x, h1 + h1p, c, sc1, sh1);
+    const float post = x.post ? x.post[n * x.C + c] : 1.f;
+    // source columns of the quad: floor(rw * wi) for wi = 4q .. 4q+3 lie in [wb, wb + 2] with wb = floor(rw * 4q); + 1 neighbour
+    const int wb = (int)(rw * (float)(4 * q));
+    float a[4], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ws = wb + j < x.W ? wb + j : x.W - 1;
+        a[j] = act1(fmaf(r0[ws], sc0, sh0), x.slope);
+        b[j] = act1(fmaf(r1[ws], sc1, sh1), x.slope);
+    }
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int wi = 4 * q + j;
+        const float w1r = rw * (float)wi;
+        const int w1 = (int)w1r;
+        const int w1p = (w1 < x.W - 1) ? 1 : 0;
+        const float w1l = w1r - (float)w1, w0l = 1.f - w1l;
+        const int d = w1 - wb;                                   // 0, 1 or 2
+        const float v00 = d == 0 ? a[0] : (d == 1 ? a[1] : a[2]);
+        const float v01 = w1p ? (d == 0 ? a[1] : (d == 1 ? a[2] : a[3])) : v00;
+        const float v10 = d == 0 ? b[0] : (d == 1 ? b[1] : b[2]);
+        const float v11 = w1p ? (d == 0 ? b[1] : (d == 1 ? b[2] : b[3])) : v10;
+        o[j] = (h0l * (w0l * v00 + w1l * v01) + h1l * (w0l * v10 + w1l * v11)) * post;
+    }
+    reinterpret_cast<float4*>(out + ((long long)pc * H2 + hi) * W2)[q] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 void launch_upsample2x(const Tensor& x, float* out, hipStream_t st) {
     const float rh = (x.H > 0) ? (float)(x.H - 1) / (float)(2 * x.H - 1) : 0.f;
     const float rw = (x.W > 0) ? (float)(x.W - 1) / (float)(2 * x.W - 1) : 0.f;
     const long long total = (long long)x.N * x.C * x.H * x.W * 4;
+    static const bool rows = !getenv("VR_NO_UP_ROWS");
+    const long long nrows = (long long)x.N * x.C * 2 * x.H;
+    if (rows && (x.W & 1) == 0 && x.W >= 8 && nrows < 0x7FFFFFFFLL && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        const int quads = 2 * x.W / 4;
+        int qp = 2;                                            // threads per row: power of two >= quads, 4 .. 256
+        while ((1 << qp) < quads && qp < 8) ++qp;
+        const int rpb = 256 >> qp;
+        hipLaunchKernelGGL(upsample2x_rows_kernel, dim3((unsigned)((nrows + rpb - 1) / rpb), qp >= 8 ? (quads + 255) / 256 : 1), dim3(256),
+                           0, st, x, out, rh, rw, qp, nrows);
+        VR_HIP(hipGetLastError());
+        return;
+    }
     if ((x.W & 1) == 0) {
         const long long tv = total / 4;
         hipLaunchKernelGGL(upsample2x_kernel<4>, dim3((unsigned)((tv + 255) / 256)), dim3(256), 0, st, x, out, rh, rw, tv);
