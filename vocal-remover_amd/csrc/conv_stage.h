@@ -32,6 +32,35 @@ __device__ __forceinline__ f32x16 mfma_bf16(s16x4 a, s16x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, b, c, 0, 0, 0);
 }
 
+// ---- fp32 products on the bf16 matrix pipe ("mfma_mode" 2): every fp32 operand x is written as the exact sum of three
+// bf16 numbers  x = x1 + x2 + x3  (x1 = bf16(x), x2 = bf16(x - x1), x3 = x - x1 - x2; each subtraction is exact, and 3 x 8
+// significand bits cover the 24 of fp32), and a*b is accumulated in fp32 as the six products
+//     a1 b1 + a2 b1 + a1 b2 + a2 b2 + a1 b3 + a3 b1;
+// the three left out (a2 b3, a3 b2, a3 b3) are below 2^-25 |a b|, i.e. under the rounding of one fp32 multiply.
+// v_mfma_f32_32x32x16_bf16 takes k = 0..7 from lanes 0-31 and k = 8..15 from lanes 32-63 (row / column = lane & 31): here
+// both k halves hold THE SAME 8 input channels, of two different planes, so one instruction adds two of the six products:
+//     A = [a1 | a2] x B = [b1 | b1],   A = [a1 | a2] x B = [b2 | b2],   A = [a1 | a3] x B = [b3 | b1]
+// = 3 instructions of 32 cycles per 8 channels where v_mfma_f32_32x32x2_f32 needs 4 of 64.
+typedef __bf16 vr_bf16x8 __attribute__((ext_vector_type(8)));
+typedef int vr_i32x4 __attribute__((ext_vector_type(4)));
+typedef int vr_i32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned vr_u32x2 __attribute__((ext_vector_type(2)));
+// one pair of fp32 values -> packed bf16 pairs of the three planes
+__device__ __forceinline__ void split3_pair(float x0, float x1, int& p1, int& p2, int& p3) {
+    vr_f32x2 v;
+    v[0] = x0; v[1] = x1;
+    p1 = __builtin_bit_cast(int, __builtin_convertvector(v, vr_bf16x2));
+    v[0] = x0 - __int_as_float(p1 << 16);
+    v[1] = x1 - __int_as_float(p1 & (int)0xffff0000);
+    p2 = __builtin_bit_cast(int, __builtin_convertvector(v, vr_bf16x2));
+    v[0] -= __int_as_float(p2 << 16);
+    v[1] -= __int_as_float(p2 & (int)0xffff0000);
+    p3 = __builtin_bit_cast(int, __builtin_convertvector(v, vr_bf16x2));
+}
+__device__ __forceinline__ f32x16 mfma_bf16x16(vr_bf16x8 a, vr_bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 // Fields of a.src[si] for a wave-uniform si, selected one by one with scalar selects: indexing the
 // by-value kernel argument dynamically makes the compiler keep a copy of it in scratch memory.
 struct SrcSel {

@@ -27,18 +27,27 @@
 
 namespace vr {
 
-template <int MT>
+// MODE: 0 = v_mfma_f32_32x32x2_f32 (exact fp32 products); 1 = bf16 operands (ConvArgs::bf16 == 1); 2 = fp32 products as six
+// bf16 products of three-way split operands (conv_stage.h).  Mode 2 keeps BOTH operands in LDS as bf16 planes, 8 input
+// channels of a (frequency, plane, row) contiguous, so the multiply phase is ds_read + MFMA only:
+//   * U arrives pre-split (wino_weights6_kernel): [f][plane][cout][8 ch] = one 16-byte operand per lane;
+//   * V is split by the transform itself: the wave transforms 4 channels x 16 tiles (lane row = channel), a 4x4 register
+//     transpose over the lane rows (v_permlane32_swap + v_permlane16_swap, 16 instructions) leaves every lane with four
+//     frequencies of all four channels of its tile, which it splits pairwise (11 VALU per pair) and stores as
+//     [f][plane][channel group][tile][4 ch] -- 12 ds_write_b64, read back as ds_read_b64.
+template <int MT, int MODE>
 struct WinoCfg {
     static constexpr int TH = 8, TW = 32, CK = 8, NT = 64;           // pixels, channels per chunk, Winograd tiles
     static constexpr int TH_in = TH + 2, XS0 = 3, TWq = 40, CSX = TH_in * TWq;
     static constexpr int WM = MT / 32;
     static constexpr int XS = CK * CSX;                                // raw input rows (single buffer)
-    static constexpr int WS = 16 * CK * MT;                            // U slab   [f][cl][m]
-    static constexpr int VS = 16 * CK * NT;                            // V slab   [f][cl][tile]
+    static constexpr bool X6 = MODE >= 2;
+    static constexpr int WS = X6 ? 16 * 3 * MT * 4 : 16 * CK * MT;     // U slab   [f][cl][m] floats;  X6: [f][plane][m][8 x bf16]
+    static constexpr int VS = X6 ? 16 * 3 * 2 * NT * 2 : 16 * CK * NT;   // V slab   [f][cl][tile] floats;  X6: [f][plane][cg][tile][4 x bf16]
     // 32 couts per workgroup: half the MFMA work per block, so the prologue (first DMA) and the epilogue weigh
     // twice as much and must overlap ANOTHER workgroup's main loop.  One V buffer (at the price of a second
     // barrier per chunk) brings the LDS footprint to 78 KB = two workgroups per CU.
-    static constexpr int NVB = MT == 32 ? 1 : 2;
+    static constexpr int NVB = (MT == 32 || X6) ? 1 : 2;             // (X6: the U planes are 1.5x the fp32 slab)
     static constexpr int LDS_FLOATS = XS + 2 * WS + NVB * VS;
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
     static constexpr int NPIECE = CSX / 4, NPASS = (NPIECE + 63) / 64;
@@ -48,10 +57,11 @@ struct WinoCfg {
     static_assert(16 * 32 * MP + 2 * MT <= LDS_FLOATS && LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <int MT, bool BF>      // BF: bf16 operands on the matrix pipe (ConvArgs::bf16), its own instantiation: a run-time branch
-                                // around the two MFMA loops costs the fp32 kernel 60 spilled registers
+template <int MT, int MODE>     // separate instantiations: a run-time branch around the MFMA loops costs the fp32 kernel
+                                // 60 spilled registers
 __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
-    using Cfg = WinoCfg<MT>;
+    using Cfg = WinoCfg<MT, MODE>;
+    constexpr bool BF = MODE == 1, X6 = MODE >= 2;
     constexpr int TH = Cfg::TH, TW = Cfg::TW, CK = Cfg::CK, NT = Cfg::NT, TWq = Cfg::TWq, CSX = Cfg::CSX, XS0 = Cfg::XS0,
                   WM = Cfg::WM, NPIECE = Cfg::NPIECE, NPASS = Cfg::NPASS, NWPASS = Cfg::NWPASS, MP = Cfg::MP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -77,6 +87,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
     const int hbase = h0 - 1, wal0 = w0 - 1 - XS0;
     const int nchunk = (a.Cin + CK - 1) / CK;
     const unsigned lds0 = (unsigned)(size_t)smem;
+    const int rot = a.rot ? (rr / a.nct) % nchunk : 0;             // chunk k of the loop is input-channel chunk (k + rot) mod nchunk
 
     // per-lane source coordinates of this wave's input pieces (see conv_dma.hip)
     unsigned hrow[NPASS], wcol4[NPASS];
@@ -90,24 +101,41 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
         wcol4[p] = ok ? (unsigned)(wi * 4) : 0x80000000u;
     }
     // weight pieces: LDS order [f][cl][m], source U[(cl*16+f)*CoutPad + m]
+    // (X6: LDS order [f][plane][m] in 16-byte operands, source U6[chunk][(f*3+plane)*CoutPad + m])
     unsigned woff[NWPASS];
 #pragma unroll
     for (int i = 0; i < NWPASS; ++i) {
         const int q = (wave + 8 * i) * 64 + lane;
-        const int m4 = q % (MT / 4), t2 = q / (MT / 4);
-        const int cl = t2 % CK, f = t2 / CK;
-        woff[i] = (unsigned)(((cl * 16 + f) * a.CoutPad + m4 * 4) * 4);
+        if constexpr (X6) {
+            const int m = q % MT, fp = q / MT;
+            woff[i] = (unsigned)((fp * a.CoutPad + m) * 16);
+        } else {
+            const int m4 = q % (MT / 4), t2 = q / (MT / 4);
+            const int cl = t2 % CK, f = t2 / CK;
+            woff[i] = (unsigned)(((cl * 16 + f) * a.CoutPad + m4 * 4) * 4);
+        }
     }
 
-    auto issue_chunk = [&](int k) {
+    auto issue_u = [&](int kl, int k, int i0, int istep) {          // weight pieces i0, i0 + istep, ... of this wave
         const int c0 = k * CK;
-        const unsigned ws_b = lds0 + (unsigned)((Cfg::XS + (k & 1) * Cfg::WS) * 4);
-        {
+        const unsigned ws_b = lds0 + (unsigned)((Cfg::XS + (kl & 1) * Cfg::WS) * 4);
+        if (a.dbg == 7) {                                                            // (ablation: no weight DMA)
+        } else if constexpr (X6) {
+            const long long chunk_bytes = 48LL * a.CoutPad * 16;
+            const char* wb = static_cast<const char*>(a.wino6) + k * chunk_bytes + (long long)co0 * 16;
+            const i32x4 wr = make_rsrc(reinterpret_cast<const float*>(wb), (unsigned)(chunk_bytes - (long long)co0 * 16));
+#pragma unroll
+            for (int i = 0; i < NWPASS; ++i)
+                if (i >= i0 && (i - i0) % istep == 0) dma16(ws_b + (wave + 8 * i) * 1024, woff[i], wr);
+        } else {
             const float* wb = a.wino + (long long)c0 * 16 * a.CoutPad + co0;
             const i32x4 wr = make_rsrc(wb, (unsigned)(((long long)(a.Cin - c0) * 16 * a.CoutPad - co0) * 4));
 #pragma unroll
             for (int i = 0; i < NWPASS; ++i) dma16(ws_b + (wave + 8 * i) * 1024, woff[i], wr);
         }
+    };
+    auto issue_x = [&](int k) {
+        const int c0 = k * CK;
         const int cl = wave;                               // this wave's input channel of the chunk
         const int ci = c0 + cl;
         if (ci >= a.Cin) {
@@ -130,9 +158,18 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
             else if (p * 64 + lane < NPIECE) dma16(cb + p * 1024, vo, xr);
         }
     };
+    // X6 issues the input rows first: they are needed by the transform, the weights only one barrier later (split waits below)
+    auto issue_chunk = [&](int kl) {
+        const int k = kl + rot < nchunk ? kl + rot : kl + rot - nchunk;
+        if (a.dbg == 6) return;                                                      // (ablation: no DMA at all)
+        if constexpr (X6) { issue_x(k); if (!a.rot2 || kl == 0) issue_u(kl, k, 0, 1); }
+        else { issue_u(kl, k, 0, 1); issue_x(k); }
+    };
 
     // input transform of this wave's channel: lane = Winograd tile (ti = lane >> 4, tj = lane & 15)
-    const int xpo = wave * CSX + (2 * (lane >> 4)) * TWq + 2 * (lane & 15) + XS0;
+    // (X6: wave = (channel group cg = wave & 1, tile row ti = wave >> 1), lane = (channel 4 cg + (lane >> 4), tj = lane & 15))
+    const int xpo = X6 ? (4 * (wave & 1) + (lane >> 4)) * CSX + (2 * (wave >> 1)) * TWq + 2 * (lane & 15) + XS0
+                       : wave * CSX + (2 * (lane >> 4)) * TWq + 2 * (lane & 15) + XS0;
     auto transform = [&](int k) {
         const float* xp = Xraw + xpo;
         float* V = VsB + (k % Cfg::NVB) * Cfg::VS + wave * NT + lane;      // + f * CK * NT
@@ -145,12 +182,50 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
             t[2][c] = d2 - d1;
             t[3][c] = d1 - d3;
         }
+        if constexpr (X6) {
+            unsigned v[16];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            V[(r * 4 + 0) * CK * NT] = t[r][0] - t[r][2];
-            V[(r * 4 + 1) * CK * NT] = t[r][1] + t[r][2];
-            V[(r * 4 + 2) * CK * NT] = t[r][2] - t[r][1];
-            V[(r * 4 + 3) * CK * NT] = t[r][1] - t[r][3];
+            for (int r = 0; r < 4; ++r) {
+                v[r * 4 + 0] = __float_as_uint(t[r][0] - t[r][2]);
+                v[r * 4 + 1] = __float_as_uint(t[r][1] + t[r][2]);
+                v[r * 4 + 2] = __float_as_uint(t[r][2] - t[r][1]);
+                v[r * 4 + 3] = __float_as_uint(t[r][1] - t[r][3]);
+            }
+            // 4x4 transpose over the lane rows: afterwards the lane of row rho holds, for i = 0..3, frequency 4 rho + i of the
+            // wave's four channels in (v[i], v[4+i], v[8+i], v[12+i])
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int j = (i & 3) + 4 * (i >> 2);                      // (0..3) with +8, (4..7) with +8
+                const vr_u32x2 q = __builtin_amdgcn_permlane32_swap(v[j], v[j + 8], false, false);
+                v[j] = q[0]; v[j + 8] = q[1];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int j = (i & 3) + 8 * (i >> 2);                      // (0..3) with +4, (8..11) with +4
+                const vr_u32x2 q = __builtin_amdgcn_permlane16_swap(v[j], v[j + 4], false, false);
+                v[j] = q[0]; v[j + 4] = q[1];
+            }
+            // dword offset of (f = 4 rho, plane 0, cg, tile): ((f * 3 + plane) * 2 + cg) * NT * 2 + tile * 2
+            unsigned* V6 = reinterpret_cast<unsigned*>(VsB) + ((4 * (lane >> 4)) * 3 * 2 + (wave & 1)) * NT * 2 +
+                           ((wave >> 1) * 16 + (lane & 15)) * 2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int h0, m0, l0, h1, m1, l1;
+                split3_pair(__uint_as_float(v[i]), __uint_as_float(v[4 + i]), h0, m0, l0);
+                split3_pair(__uint_as_float(v[8 + i]), __uint_as_float(v[12 + i]), h1, m1, l1);
+                unsigned* q = V6 + i * 3 * 2 * NT * 2;
+                *reinterpret_cast<vr_i32x2*>(q) = vr_i32x2{h0, h1};
+                *reinterpret_cast<vr_i32x2*>(q + 2 * NT * 2) = vr_i32x2{m0, m1};
+                *reinterpret_cast<vr_i32x2*>(q + 4 * NT * 2) = vr_i32x2{l0, l1};
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                V[(r * 4 + 0) * CK * NT] = t[r][0] - t[r][2];
+                V[(r * 4 + 1) * CK * NT] = t[r][1] + t[r][2];
+                V[(r * 4 + 2) * CK * NT] = t[r][2] - t[r][1];
+                V[(r * 4 + 3) * CK * NT] = t[r][1] - t[r][3];
+            }
         }
     };
 
@@ -167,6 +242,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
 
     issue_chunk(0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if constexpr (X6) lds_barrier();                     // the transform reads channels other waves fetched
     transform(0);
     lds_barrier();
 
@@ -176,7 +252,85 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
         if (k + 1 < nchunk) issue_chunk(k + 1);
         const float* Ws = WsB + (k & 1) * Cfg::WS + (2 * wave) * CK * MT + aoff;
         const float* Vs = VsB + (k % Cfg::NVB) * Cfg::VS + (2 * wave) * CK * NT + boff;
-        if constexpr (BF) {
+        if constexpr (X6) {
+            // three v_mfma_f32_32x32x16_bf16 per (frequency, cout tile, pixel tile) cover the chunk's 8 input channels
+            if (a.dbg != 2) {
+                const char* Ub = reinterpret_cast<const char*>(WsB + (k & 1) * Cfg::WS) + (2 * wave) * 3 * MT * 16 + l31 * 16;
+                const char* Vb = reinterpret_cast<const char*>(VsB) + (2 * wave) * 3 * 2 * NT * 8 + l31 * 8;
+                const int a12 = khalf * MT * 16, a13 = khalf * 2 * MT * 16;       // lanes 32-63: plane 2 resp. plane 3 of U
+                const int b3 = khalf ? 0 : 2 * 2 * NT * 8;                        // [b3 | b1]
+#pragma unroll
+                for (int fi = 0; fi < 2; ++fi) {
+                    vr_bf16x8 A12[WM], A13[WM];
+#pragma unroll
+                    for (int mi = 0; mi < WM; ++mi) {
+                        const char* q = Ub + (fi * 3 * MT + mi * 32) * 16;
+                        A12[mi] = *reinterpret_cast<const vr_bf16x8*>(q + a12);
+                        A13[mi] = *reinterpret_cast<const vr_bf16x8*>(q + a13);
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        const char* q = Vb + fi * 3 * 2 * NT * 8 + ni * 32 * 8;
+                        vr_i32x4 p1, p2, p3;
+                        if constexpr (MODE == 3) {
+                            // hand-issued: six ds_read_b64 (256 B/clk) where the compiler pairs them into ds_read2_b64 (128 B/clk)
+                            const unsigned qa = (unsigned)(size_t)Vb, qb = qa + (unsigned)b3;
+                            constexpr int o = 0;
+                            vr_i32x2 x0, x1, y0, y1, z0, z1;
+#define VR_LDS64(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+                            if (fi == 0 && ni == 0) {
+                                VR_LDS64(x0, qa, 0); VR_LDS64(x1, qa, NT * 8); VR_LDS64(y0, qa, 2 * NT * 8); VR_LDS64(y1, qa, 3 * NT * 8);
+                                VR_LDS64(z0, qb, 0); VR_LDS64(z1, qb, NT * 8);
+                            } else if (fi == 0 && ni == 1) {
+                                VR_LDS64(x0, qa, 256); VR_LDS64(x1, qa, 256 + NT * 8); VR_LDS64(y0, qa, 256 + 2 * NT * 8); VR_LDS64(y1, qa, 256 + 3 * NT * 8);
+                                VR_LDS64(z0, qb, 256); VR_LDS64(z1, qb, 256 + NT * 8);
+                            } else if (fi == 1 && ni == 0) {
+                                VR_LDS64(x0, qa, 6 * NT * 8); VR_LDS64(x1, qa, 7 * NT * 8); VR_LDS64(y0, qa, 8 * NT * 8); VR_LDS64(y1, qa, 9 * NT * 8);
+                                VR_LDS64(z0, qb, 6 * NT * 8); VR_LDS64(z1, qb, 7 * NT * 8);
+                            } else {
+                                VR_LDS64(x0, qa, 256 + 6 * NT * 8); VR_LDS64(x1, qa, 256 + 7 * NT * 8); VR_LDS64(y0, qa, 256 + 8 * NT * 8);
+                                VR_LDS64(y1, qa, 256 + 9 * NT * 8); VR_LDS64(z0, qb, 256 + 6 * NT * 8); VR_LDS64(z1, qb, 256 + 7 * NT * 8);
+                            }
+#undef VR_LDS64
+                            (void)o; (void)q;
+                            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1), "+v"(z0), "+v"(z1));
+                            p1 = vr_i32x4{x0[0], x0[1], x1[0], x1[1]};
+                            p2 = vr_i32x4{y0[0], y0[1], y1[0], y1[1]};
+                            p3 = vr_i32x4{z0[0], z0[1], z1[0], z1[1]};
+                        } else {
+                            {
+                                const vr_i32x2 x0 = *reinterpret_cast<const vr_i32x2*>(q), x1 = *reinterpret_cast<const vr_i32x2*>(q + NT * 8);
+                                p1 = vr_i32x4{x0[0], x0[1], x1[0], x1[1]};
+                            }
+                            {
+                                const char* q2 = q + 2 * NT * 8;
+                                const vr_i32x2 x0 = *reinterpret_cast<const vr_i32x2*>(q2), x1 = *reinterpret_cast<const vr_i32x2*>(q2 + NT * 8);
+                                p2 = vr_i32x4{x0[0], x0[1], x1[0], x1[1]};
+                            }
+                            {
+                                const char* q3 = q + b3;
+                                const vr_i32x2 x0 = *reinterpret_cast<const vr_i32x2*>(q3), x1 = *reinterpret_cast<const vr_i32x2*>(q3 + NT * 8);
+                                p3 = vr_i32x4{x0[0], x0[1], x1[0], x1[1]};
+                            }
+                        }
+                        const vr_bf16x8 B1 = __builtin_bit_cast(vr_bf16x8, p1), B2 = __builtin_bit_cast(vr_bf16x8, p2),
+                                        B3 = __builtin_bit_cast(vr_bf16x8, p3);
+#pragma unroll
+                        for (int mi = 0; mi < WM; ++mi) acc[fi][mi][ni] = mfma_bf16x16(A12[mi], B1, acc[fi][mi][ni]);
+#pragma unroll
+                        for (int mi = 0; mi < WM; ++mi) acc[fi][mi][ni] = mfma_bf16x16(A12[mi], B2, acc[fi][mi][ni]);
+#pragma unroll
+                        for (int mi = 0; mi < WM; ++mi) acc[fi][mi][ni] = mfma_bf16x16(A13[mi], B3, acc[fi][mi][ni]);
+                        // (experiment, ConvArgs::rot2: the weight pieces of chunk k+1 are issued between the MFMA groups, not in
+                        // one burst of 8 waves x NWPASS at the top of the phase)
+                        if (a.rot2 && k + 1 < nchunk && a.dbg != 6) {
+                            const int kn = k + 1 + rot < nchunk ? k + 1 + rot : k + 1 + rot - nchunk;
+                            issue_u(k + 1, kn, fi * 2 + ni, 4);
+                        }
+                    }
+                }
+            }
+        } else if constexpr (BF) {
             // bf16 operands: one v_mfma_f32_32x32x8_bf16 covers the chunk's 8 input channels of a frequency
             const float* Wb = WsB + (k & 1) * Cfg::WS + (2 * wave) * CK * MT + (4 * khalf) * MT + l31;
             const float* Vb = VsB + (k % Cfg::NVB) * Cfg::VS + (2 * wave) * CK * NT + (4 * khalf) * NT + l31;
@@ -232,9 +386,16 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
             }
         }
         if (k + 1 < nchunk) {
-            if (Cfg::NVB == 1) lds_barrier();                              // every wave is done reading V(k)
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's channel of chunk k+1 has landed
+            if constexpr (X6) {
+                // this wave's channel of chunk k+1 has landed (its NWPASS weight pieces, issued after it, may still be in flight) ...
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(NWPASS) : "memory");
+                lds_barrier();                                               // ... so has everybody's, and V(k) has been read
+            } else {
+                if (Cfg::NVB == 1) lds_barrier();                              // every wave is done reading V(k)
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's channel of chunk k+1 has landed
+            }
             if (a.dbg != 3) transform(k + 1);
+            if constexpr (X6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weights of chunk k+1
         }
         lds_barrier();
     }
@@ -361,10 +522,57 @@ void launch_wino_weights(const float* w, float* u, int Cin, int CoutPad, hipStre
     VR_HIP(hipGetLastError());
 }
 
-template <int MT, bool BF>
+// The same U as three bf16 planes (conv_stage.h): u6 [ceil(Cin/8)][16][3][CoutPad][8 channels], zero for channels >= Cin.
+__global__ void wino_weights6_kernel(const float* __restrict__ w, unsigned short* __restrict__ u6, int Cin, int CoutPad) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cin8 = (Cin + 7) / 8 * 8;
+    if (gid >= (long long)cin8 * CoutPad) return;
+    const int co = (int)(gid % CoutPad);
+    const int ci = (int)(gid / CoutPad);
+    float g[3][3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) g[i / 3][i % 3] = ci < Cin ? w[((long long)ci * 9 + i) * CoutPad + co] : 0.f;
+    float t[4][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        t[0][c] = g[0][c];
+        t[1][c] = 0.5f * (g[0][c] + g[1][c] + g[2][c]);
+        t[2][c] = 0.5f * (g[0][c] - g[1][c] + g[2][c]);
+        t[3][c] = g[2][c];
+    }
+    unsigned short* o = u6 + (((long long)(ci >> 3) * 48) * CoutPad + co) * 8 + (ci & 7);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float u[4];
+        u[0] = t[r][0];
+        u[1] = 0.5f * (t[r][0] + t[r][1] + t[r][2]);
+        u[2] = 0.5f * (t[r][0] - t[r][1] + t[r][2]);
+        u[3] = t[r][2];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            int p1, p2, p3;
+            split3_pair(u[c], 0.f, p1, p2, p3);
+            const long long f = r * 4 + c;
+            o[(f * 3 + 0) * CoutPad * 8] = (unsigned short)(p1 & 0xffff);
+            o[(f * 3 + 1) * CoutPad * 8] = (unsigned short)(p2 & 0xffff);
+            o[(f * 3 + 2) * CoutPad * 8] = (unsigned short)(p3 & 0xffff);
+        }
+    }
+}
+
+size_t wino_weights6_bytes(int Cin, int CoutPad) { return (size_t)((Cin + 7) / 8) * 48 * CoutPad * 16; }
+
+void launch_wino_weights6(const float* w, void* u6, int Cin, int CoutPad, hipStream_t st) {
+    const long long n = (long long)((Cin + 7) / 8 * 8) * CoutPad;
+    hipLaunchKernelGGL(wino_weights6_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w,
+                       static_cast<unsigned short*>(u6), Cin, CoutPad);
+    VR_HIP(hipGetLastError());
+}
+
+template <int MT, int MODE>
 static void wino_launch(const ConvArgs& a, hipStream_t st) {
-    using Cfg = WinoCfg<MT>;
-    auto kern = conv_wino_kernel<MT, BF>;
+    using Cfg = WinoCfg<MT, MODE>;
+    auto kern = conv_wino_kernel<MT, MODE>;
     static std::atomic<unsigned long long> attr_done{0};          // per device (bit = device index)
     ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
     const int groups = (a.npt + 7) / 8;
@@ -387,6 +595,7 @@ bool wino_pick(const ConvArgs& a, const ConvShape& s, int* MT_out) {
         if ((long long)c.H * (c.sH > 0 ? c.sH : 1) * 4 >= 0x7FFFFFF0LL) return false;
     }
     if ((long long)a.Cin * 16 * a.CoutPad * 4 >= 0x7FFFFFF0LL) return false;
+    if (a.bf16 == 2 && !a.wino6) return false;
     const long long tiles = (long long)a.N * ((a.Hout + 7) / 8) * ((a.Wout + 31) / 32);
     int MT = (a.CoutPad % 64 == 0) ? 64 : 32;
     static const int min64 = getenv("VR_WINO_MIN64") ? atoi(getenv("VR_WINO_MIN64")) : 384;
@@ -406,11 +615,21 @@ void wino_fill_tiling(ConvArgs& a, int MT) {
     a.nct = a.CoutPad / MT;
 }
 
-void wino_launch_conv(const ConvArgs& a, int MT, hipStream_t st) {
-    if (a.bf16) {
-        if (MT == 64) wino_launch<64, true>(a, st); else wino_launch<32, true>(a, st);
+void wino_launch_conv(const ConvArgs& a_in, int MT, hipStream_t st) {
+    static const int rot = getenv("VR_WINO_ROT") ? atoi(getenv("VR_WINO_ROT")) : 0;
+    ConvArgs a = a_in;
+    a.rot = rot;
+    static const int rot2 = getenv("VR_X6_ILV") ? atoi(getenv("VR_X6_ILV")) : 0;
+    a.rot2 = rot2;
+    static const int x6_min_mt = getenv("VR_X6_MIN_MT") ? atoi(getenv("VR_X6_MIN_MT")) : 32;    // (experiments: 64 keeps the 32-cout variant on fp32 MFMAs)
+    static const int x6_vol = getenv("VR_X6_VOL") ? atoi(getenv("VR_X6_VOL")) : 0;
+    if (a.bf16 == 2 && a.wino6 && MT >= x6_min_mt) {
+        if (x6_vol) { if (MT == 64) wino_launch<64, 3>(a, st); else wino_launch<32, 3>(a, st); }
+        else { if (MT == 64) wino_launch<64, 2>(a, st); else wino_launch<32, 2>(a, st); }
+    } else if (a.bf16 == 1) {
+        if (MT == 64) wino_launch<64, 1>(a, st); else wino_launch<32, 1>(a, st);
     } else {
-        if (MT == 64) wino_launch<64, false>(a, st); else wino_launch<32, false>(a, st);
+        if (MT == 64) wino_launch<64, 0>(a, st); else wino_launch<32, 0>(a, st);
     }
 }
 

@@ -16,7 +16,9 @@ struct HeadDst {
 };
 void launch_head_sigmoid(const Tensor& x, const float* w /*[2][C]*/, const HeadDst& d, hipStream_t st);
 // out[n][0][h][w] = sum_c w[c] * act(x);  part: [nblocks][2] (sum, sumsq) or null; returns nblocks
-int launch_squeeze_conv(const Tensor& x, const float* w /*[C]*/, float* out, float* part, bool dry, hipStream_t st);
+// epi (eval): device [2] = folded (scale, shift) of the single-channel BatchNorm, applied with the ReLU before the store
+int launch_squeeze_conv(const Tensor& x, const float* w /*[C]*/, float* out, float* part, bool dry, hipStream_t st,
+                        const float* epi = nullptr);
 
 // mean over H of act(x) -> out [N][C][W]  (AdaptiveAvgPool2d((1, None)), lib/layers.py:72)
 void launch_avgpool_h(const Tensor& x, float* out, hipStream_t st);
@@ -49,6 +51,8 @@ void launch_augment(const float2* X, const float2* Y, const float2* Xi, const fl
                     int B, int T, int bins, float* Xmag, float* Ymag, hipStream_t st);
 void launch_s2_class_weights(const float* w, float* wc, int Cin, int Cout, int CoutPad, int CinPad, hipStream_t st);
 void launch_wino_weights(const float* w, float* u, int Cin, int CoutPad, hipStream_t st);   // U = G g G^T
+size_t wino_weights6_bytes(int Cin, int CoutPad);                                           // U as three bf16 planes (mfma_mode 2)
+void launch_wino_weights6(const float* w, void* u6, int Cin, int CoutPad, hipStream_t st);
 void launch_upsample2x(const Tensor& x, float* out, hipStream_t st);   // dense [N][C][2H][2W], activated
 
 // ---- lstm.hip -----------------------------------------------------------------------------------

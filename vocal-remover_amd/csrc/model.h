@@ -62,6 +62,7 @@ struct Conv {
     BN* bn = nullptr;
     float slope = 0.f;              // activation after the BatchNorm
     float* wino = nullptr;          // eval: Winograd-transformed weights [Cin][16][CoutPad] (3x3 stride-1 layers)
+    void* wino6 = nullptr;          // mfma_mode 2: the same as three bf16 planes (conv_wino.hip: wino_weights6_kernel)
 };
 
 struct LSTMMod {
@@ -148,7 +149,10 @@ public:
                      int B, int T, int bins, bool in_on_dev, float* Xmag, float* ymag, bool out_on_dev);
     char* aug_buf = nullptr; size_t aug_cap = 0;         // staging of the training input pipeline
     bool train_wino = true;                              // vr_set_option("train_winograd"): Winograd kernels in train mode
-    bool mfma_bf16 = false;                              // vr_set_option("mfma_bf16"): bf16 operands on the matrix pipe (configs[4])
+    // vr_set_option("mfma_mode"): how the Winograd kernels multiply.  0 = v_mfma_f32_32x32x2_f32 (exact fp32 products);
+    // 1 = operands rounded to bf16 (configs[4]; "mfma_bf16" 1 is the same); 2 = fp32 products as six bf16 products of
+    // three-way split operands, fp32 accumulation (conv_stage.h) -- forward and data-gradient convs, weight gradients stay on 0.
+    int mfma_mode = 0;
     bool serial = false;                                 // vr_set_option("serial_exec"): no lanes / side streams (tests: race detector)
     void set_option(const std::string& name, int value);
     void reset_adam_state();
@@ -183,6 +187,9 @@ private:
     float* wino_arena = nullptr;
     float* winot_arena = nullptr;                        // training: Winograd copies of the flipped/transposed weights
     std::map<const Param*, float*> winot_of;
+    char* wino6_arena = nullptr;                         // mfma_mode 2: bf16-plane copies of both
+    char* winot6_arena = nullptr;
+    std::map<const Param*, void*> winot6_of;
     void refresh_wino(bool with_dgrad);
     BNFoldDesc* d_fold = nullptr;
     bool affine_dirty = true;

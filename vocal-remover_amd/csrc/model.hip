@@ -126,6 +126,7 @@ Model::Model(int device_, int n_fft_, int hop_, int nout_, int nout_lstm_)
     output_bin = n_fft / 2 + 1;
     VR_CHECK((max_bin / 2) % 16 == 0, -2, "n_fft/4 must be a multiple of 16 (four stride-2 encoders)");
     DeviceGuard dev_guard(device);
+    if (const char* e = getenv("VR_MFMA_MODE")) { mfma_mode = atoi(e); VR_CHECK(mfma_mode >= 0 && mfma_mode <= 2, -2, "VR_MFMA_MODE: 0, 1 or 2"); }
     VR_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     if (!getenv("VR_NO_SIDE_STREAM")) {
         VR_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
@@ -241,7 +242,7 @@ Model::~Model() {
     hipFree(wire_buf);
     if (stream) hipStreamSynchronize(stream);
     hipFree(p_arena); hipFree(b_arena); hipFree(d_fold);
-    hipFree(ws.base); hipFree(io.base); hipFree(gs.base); hipFree(wino_arena); hipFree(winot_arena); hipFree(aug_buf);
+    hipFree(ws.base); hipFree(io.base); hipFree(gs.base); hipFree(wino_arena); hipFree(winot_arena); hipFree(wino6_arena); hipFree(winot6_arena); hipFree(aug_buf);
     hipFree(g_arena); hipFree(m_arena); hipFree(v_arena); hipFree(wt_arena); hipFree(d_flip); hipFree(dropout_buf);
     hipFree(plan.twiddle); hipFree(plan.window);
     for (Lane& l : lanes) {
@@ -335,7 +336,11 @@ void Model::set_option(const std::string& name, int value) {
     if (name == "train_winograd") train_wino = value != 0;
     else if (name == "serial_exec") serial = value != 0;     // every kernel on the handle's one stream (race detector of the tests)
     else if (name == "params_dirty") affine_dirty = true;    // the parameter arena was written from outside (vr_param_arena)
-    else if (name == "mfma_bf16") mfma_bf16 = value != 0;    // bf16 operands on the matrix pipe, fp32 storage / accumulation
+    else if (name == "mfma_bf16") { mfma_mode = value != 0 ? 1 : 0; affine_dirty = true; }   // bf16 operands on the matrix pipe, fp32 storage / accumulation
+    else if (name == "mfma_mode") {                          // 0 exact fp32 MFMA, 1 bf16 operands, 2 fp32 via 6 bf16 products (model.h)
+        if (value < 0 || value > 2) throw Error(-2, "mfma_mode: 0, 1 or 2");
+        mfma_mode = value; affine_dirty = true;              // (the next eval forward refreshes the Winograd weight copies)
+    }
     else if (name == "adam_reset") reset_adam_state();      // a freshly constructed torch.optim.Adam has no moments
     else throw Error(-2, "unknown option: " + name);
 }
@@ -351,8 +356,31 @@ void Model::refresh_wino(bool with_dgrad) {
         for (Conv* L : wino_list) { L->wino = wino_arena + off; off += (size_t)L->Cin * 16 * L->CoutPad; }
     }
     for (Conv* L : wino_list) launch_wino_weights(L->w->dev, L->wino, L->Cin, L->CoutPad, stream);
-    if (!with_dgrad) return;
     auto cin_pad = [](const Conv* L) { return (L->Cin + 31) / 32 * 32; };
+    if (mfma_mode == 2) {
+        if (!wino6_arena) {
+            size_t total = 0;
+            for (Conv* L : wino_list) total += wino_weights6_bytes(L->Cin, L->CoutPad);
+            VR_HIP(hipMalloc(reinterpret_cast<void**>(&wino6_arena), total));
+            size_t off = 0;
+            for (Conv* L : wino_list) { L->wino6 = wino6_arena + off; off += wino_weights6_bytes(L->Cin, L->CoutPad); }
+        }
+        for (Conv* L : wino_list) launch_wino_weights6(L->w->dev, L->wino6, L->Cin, L->CoutPad, stream);
+        if (with_dgrad) {
+            if (!winot6_arena) {
+                size_t total = 0;
+                for (Conv* L : wino_list) total += wino_weights6_bytes(L->Cout, cin_pad(L));
+                VR_HIP(hipMalloc(reinterpret_cast<void**>(&winot6_arena), total));
+                size_t off = 0;
+                for (Conv* L : wino_list) { winot6_of[L->w] = winot6_arena + off; off += wino_weights6_bytes(L->Cout, cin_pad(L)); }
+            }
+            for (Conv* L : wino_list) {
+                auto it = wt_of.find(L->w);
+                if (it != wt_of.end()) launch_wino_weights6(it->second, winot6_of[L->w], L->Cout, cin_pad(L), stream);
+            }
+        }
+    }
+    if (!with_dgrad) return;
     if (!winot_arena) {
         size_t total = 0;
         for (Conv* L : wino_list) total += (size_t)L->Cout * 16 * cin_pad(L);
@@ -567,7 +595,8 @@ Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs_in, int N, cons
     const bool fuse_epi = !training && L.bn != nullptr;
     if (fuse_epi) { a.epi = L.bn->affine; a.epi_slope = L.slope; }
     a.wino = (training && !train_wino) ? nullptr : L.wino;   // (null until the first refresh_wino())
-    a.bf16 = mfma_bf16 ? 1 : 0;
+    a.wino6 = (a.wino && mfma_mode == 2) ? L.wino6 : nullptr;
+    a.bf16 = mfma_mode;
     Tensor o;
     if (batch_as_h) {
         o.N = N; o.C = L.Cout; o.H = 1; o.W = a.Wout;
@@ -639,7 +668,8 @@ Tensor Model::run_lstm(LSTMMod& M, const Tensor& h) {
     const int nblk = launch_squeeze_conv(h, M.squeeze.w->dev, z, nullptr, true, stream);
     float* part = training ? ws.allocf((size_t)nblk * 2) : nullptr;
     if (!dry) {
-        launch_squeeze_conv(h, M.squeeze.w->dev, z, part, false, stream);
+        // eval: BatchNorm (running statistics, folded) + ReLU in the kernel's store, so the LSTM input projection reads a plain tensor
+        launch_squeeze_conv(h, M.squeeze.w->dev, z, part, false, stream, training ? nullptr : M.squeeze.bn->affine);
         if (training) {
             BN* b = M.squeeze.bn;
             BNFinalizeArgs f{};
@@ -655,7 +685,8 @@ Tensor Model::run_lstm(LSTMMod& M, const Tensor& h) {
     Tensor zt;
     zt.p = z; zt.N = N; zt.C = nb; zt.H = 1; zt.W = nf;
     zt.sN = (long long)nb * nf; zt.sC = nf; zt.sH = nf;
-    zt.aff0 = M.squeeze.bn->affine; zt.slope = 0.f;
+    if (training) { zt.aff0 = M.squeeze.bn->affine; zt.slope = 0.f; }
+    else zt.slope = 1.f;
     if (taping()) {
         zt.g = gs.allocf((size_t)N * nb * nf);
         TapeRec r;
@@ -1319,13 +1350,19 @@ void Model::debug_conv(const float* x, int N, int Cin, int H, int W, const float
     a.nsrc = 1; a.src[0] = make_src(t, up != 0, 0); a.c1 = a.c2 = Cin; a.Cin = Cin;
     a.w = dw_; a.bias = dbias; a.Cout = Cout; a.CoutPad = CoutPad;
     if (epi && daff) { a.epi = daff; a.epi_slope = slope; }
-    a.bf16 = mfma_bf16 ? 1 : 0;
+    a.bf16 = mfma_mode;
     float* dwino = nullptr;
+    void* dwino6 = nullptr;
     if (want_wino) {
         VR_CHECK(KS == 3 && stride == 1 && dh == 1 && dw == 1, -2, "Winograd weights exist for 3x3 stride-1 convs only");
         VR_HIP(hipMalloc(&dwino, (size_t)Cin * 16 * CoutPad * 4));
         launch_wino_weights(dw_, dwino, Cin, CoutPad, stream);
         a.wino = dwino;
+        if (mfma_mode == 2) {
+            VR_HIP(hipMalloc(&dwino6, wino_weights6_bytes(Cin, CoutPad)));
+            launch_wino_weights6(dw_, dwino6, Cin, CoutPad, stream);
+            a.wino6 = dwino6;
+        }
     }
     a.dst[0] = ConvDst{dout, (long long)Hout * Wout * Cout, (long long)Hout * Wout, (long long)Wout, 0};
     a.d1 = a.d2 = 1 << 30;
@@ -1345,7 +1382,7 @@ void Model::debug_conv(const float* x, int N, int Cin, int H, int W, const float
             stats_out[2 * c] = (float)s1; stats_out[2 * c + 1] = (float)s2;
         }
     }
-    hipFree(dx); hipFree(dw_); hipFree(dout); hipFree(daff); hipFree(dbias); hipFree(dpart); hipFree(dwino);
+    hipFree(dx); hipFree(dw_); hipFree(dout); hipFree(daff); hipFree(dbias); hipFree(dpart); hipFree(dwino); hipFree(dwino6);
 }
 
 }  // namespace vr

@@ -22,7 +22,7 @@ __device__ __forceinline__ void load_aff(const Tensor& x, int h, int c, float& s
 // ---------------------------------------------------------------------------------------------------
 template <int CO, bool FINAL>
 __global__ __launch_bounds__(256) void thin_conv_kernel(Tensor x, const float* __restrict__ w, HeadDst d,
-                                                        float* out, float* part) {
+                                                        float* out, float* part, const float* __restrict__ epi) {
     const int W4 = x.W >> 2;
     const long long total = (long long)x.N * x.H * W4;
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -66,6 +66,11 @@ __global__ __launch_bounds__(256) void thin_conv_kernel(Tensor x, const float* _
                 }
             }
         } else {
+            if (epi) {           // eval: the single-channel BatchNorm (folded scale, shift) + ReLU here, so the stored row is final
+                const float esc = epi[0], esh = epi[1];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[0][j] = fmaxf(fmaf(acc[0][j], esc, esh), 0.f);
+            }
             float4 o4 = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
             *reinterpret_cast<float4*>(out + ((long long)n * x.H + h) * x.W + w4 * 4) = o4;
 #pragma unroll
@@ -98,17 +103,17 @@ void launch_head_sigmoid(const Tensor& x, const float* w, const HeadDst& d, hipS
     check_vec4(x);
     const long long total = (long long)x.N * x.H * (x.W / 4);
     const int grid = (int)((total + 255) / 256);
-    hipLaunchKernelGGL((thin_conv_kernel<2, true>), dim3(grid), dim3(256), 0, st, x, w, d, nullptr, nullptr);
+    hipLaunchKernelGGL((thin_conv_kernel<2, true>), dim3(grid), dim3(256), 0, st, x, w, d, nullptr, nullptr, nullptr);
     VR_HIP(hipGetLastError());
 }
 
-int launch_squeeze_conv(const Tensor& x, const float* w, float* out, float* part, bool dry, hipStream_t st) {
+int launch_squeeze_conv(const Tensor& x, const float* w, float* out, float* part, bool dry, hipStream_t st, const float* epi) {
     const long long total = (long long)x.N * x.H * (x.W / 4);
     const int grid = (int)((total + 255) / 256);
     if (dry) return grid;
     check_vec4(x);
     HeadDst d{};
-    hipLaunchKernelGGL((thin_conv_kernel<1, false>), dim3(grid), dim3(256), 0, st, x, w, d, out, part);
+    hipLaunchKernelGGL((thin_conv_kernel<1, false>), dim3(grid), dim3(256), 0, st, x, w, d, out, part, epi);
     VR_HIP(hipGetLastError());
     return grid;
 }

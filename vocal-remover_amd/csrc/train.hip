@@ -166,7 +166,7 @@ void Model::bwd_conv(TapeRec& r) {
         else { w.zN = out.sN; w.zC = out.sC; w.zH = out.sH; }
         w.Cout = L.Cout; w.CoutPad = L.CoutPad;
         w.allow_wino = train_wino ? 1 : 0;
-        w.bf16 = mfma_bf16 ? 1 : 0;
+        w.bf16 = mfma_mode == 1 ? 1 : 0;
         w.part = ws.allocf(wgrad_scratch_floats(w, shp));
         if (!dry) {
             // The weight gradient is off the critical path (dz -> data gradient -> previous layer): it runs on the
@@ -201,9 +201,11 @@ void Model::bwd_conv(TapeRec& r) {
     {
         auto it = winot_of.find(L.w);
         d.wino = (!dry && train_wino && it != winot_of.end()) ? it->second : nullptr;
+        auto it6 = winot6_of.find(L.w);
+        d.wino6 = (d.wino && mfma_mode == 2 && it6 != winot6_of.end()) ? it6->second : nullptr;
     }
     d.bias = nullptr;
-    d.bf16 = mfma_bf16 ? 1 : 0;
+    d.bf16 = mfma_mode;
     d.Cout = L.Cin; d.CoutPad = round_up32(L.Cin);
     d.N = f.N; d.Hin = f.Hin; d.Win = f.Win; d.Hout = f.Hin; d.Wout = f.Win;
     d.pad_h = (L.KS == 1) ? 0 : L.dh; d.pad_w = (L.KS == 1) ? 0 : L.dw;
@@ -252,7 +254,7 @@ void Model::bwd_conv(TapeRec& r) {
                 ConvArgs k = c;
                 k.Hout = (f.Hin - ph + 1) / 2; k.Wout = (f.Win - pw + 1) / 2;
                 k.w = it->second + cls * cls_stride;
-                k.wino = nullptr;
+                k.wino = nullptr; k.wino6 = nullptr;
                 int tm = 0;
                 for (int th = 0; th < 3; ++th)
                     for (int tw = 0; tw < 3; ++tw)
