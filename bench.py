@@ -312,6 +312,24 @@ def main():
         train_roof = roofline(train_step_fn, CONV_FAMILY_TRAIN, 'r02_train_pmc.json')
         bf_res, _ = run_train(True)
         net.set_option('mfma_bf16', 0)
+        # the exact-fp32-by-split-bf16 multiply mode of the 64-cout Winograd kernel, beside the v_mfma_f32_32x32x2_f32 numbers above
+        net.set_option('mfma_mode', 2)
+        sp_inf, _ = run_infer(False)
+        net.set_option('mfma_mode', 2)          # (run_train resets the mode through 'mfma_bf16')
+        sp_trn = None
+        try:
+            from vocal_remover_amd import train as vtrain
+            trainer = vtrain.Trainer(net, lr=1e-3, world_size=world, rank=rank, backend='rccl' if world > 1 else 'none',
+                                     wire=args.wire if world > 1 else 'fp32')
+            g = torch.Generator().manual_seed(rank)
+            B = args.train_batch
+            Xs = torch.rand((B, 2, N_FFT // 2 + 1, CROP), generator=g)
+            ys = (Xs * torch.rand((B, 2, N_FFT // 2 + 1, CROP), generator=g)).to(dev)
+            Xs = Xs.to(dev)
+            dts = timed(lambda: trainer.step(Xs, ys), args.steps, args.warmup)
+            sp_trn = {'frames_per_sec': world * B * CROP * args.steps / dts, 'ms_per_step': dts / args.steps * 1e3}
+        finally:
+            net.set_option('mfma_mode', 0)
         net.eval()
         if rank == 0:
             out['config']['pcie_inclusive_frames_per_sec'] = extra.get('pcie_inclusive_frames_per_sec')
@@ -327,6 +345,13 @@ def main():
                                  'value': bf_res['frames_per_sec'], 'ms_per_step': bf_res['ms_per_step'], 'steps': args.steps,
                                  'warmup': args.warmup, 'global_batch': bf_res['global_batch'], 'workload': bf_res['workload'],
                                  'parallelism': bf_res['parallelism'], 'dtype': bf_res['dtype']}
+            out['split_bf16'] = {
+                'what': "vr_set_option('mfma_mode', 2): the 64-cout Winograd forward / data-gradient kernel forms every fp32 product as six "
+                        'bf16 products of three-way split operands on v_mfma_f32_32x32x16_bf16, fp32 accumulation; error vs fp64 equal to '
+                        'the fp32-MFMA kernel (tests/test_gpu_parity.py::test_conv_winograd_split_bf16_mode_is_fp32_exact); default is mode 0',
+                'dtype': 'f32 (bf16x3 split, 6 products, fp32 accumulate)',
+                'infer': {'value': sp_inf['frames_per_sec'], 'ms_per_step': sp_inf['ms_per_step']},
+                'train': {'value': sp_trn['frames_per_sec'], 'ms_per_step': sp_trn['ms_per_step']} if sp_trn else None}
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

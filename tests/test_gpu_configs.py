@@ -137,18 +137,33 @@ def test_full_net_train_step(vr, full):
                                             dropout={k: v.double() for k, v in masks.items()})
     sd32 = weights.clone_state_dict(sd)
     loss32, g32 = train_step.loss_and_grads(sd32, X, y, n_fft=N_FFT, dropout=masks)
-    try:
-        model.load_state_dict(sd)
-        model.train()
-        model.set_dropout_masks(masks)
-        model.zero_grad()
-        loss, mask = model.train_step(X.to('cuda:0'), y.to('cuda:0'), 1, return_mask=True)
-        grads = model.grads()
-        state = model.state_dict()
-    finally:
-        model.set_dropout_masks(None)
-        model.load_state_dict(sd)
-        model.eval()
+    sdm = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    want_mask = cascaded_net.forward(X.double(), sdm, n_fft=N_FFT, training=True, update_running=False,
+                                     dropout={k: v.double() for k, v in masks.items()})
+    # train-mode BatchNorm over a batch of 2 amplifies fp32 rounding: the bar is the fp32 CPU oracle's own deviation
+    mask32 = cascaded_net.forward(X, weights.clone_state_dict(sd), n_fft=N_FFT, training=True, update_running=False, dropout=masks)
+    e32 = float((mask32.double() - want_mask).abs().max())
+    # mfma_mode 0 = fp32 MFMAs; 2 = fp32 products as six bf16 products of split operands (forward + data-gradient Winograd
+    # convs): the SAME bars for both
+    for mode in (0, 2):
+        try:
+            model.load_state_dict(sd)
+            model.set_option('mfma_mode', mode)
+            model.train()
+            model.set_dropout_masks(masks)
+            model.zero_grad()
+            loss, mask = model.train_step(X.to('cuda:0'), y.to('cuda:0'), 1, return_mask=True)
+            grads = model.grads()
+            state = model.state_dict()
+        finally:
+            model.set_dropout_masks(None)
+            model.set_option('mfma_mode', 0)
+            model.load_state_dict(sd)
+            model.eval()
+        _check_full_net_train_step(mode, loss, mask, grads, state, loss64, g64, g32, sd64, want_mask, e32)
+
+
+def _check_full_net_train_step(mode, loss, mask, grads, state, loss64, g64, g32, sd64, want_mask, e32):
     assert abs(loss - loss64) < 2e-6, (loss, loss64)
     report, bad = [], []
     for k in g64:
@@ -164,7 +179,7 @@ def test_full_net_train_step(vr, full):
     print('\n'.join('%-60s gpu %.3e  cpu32 %.3e' % (k, a, b) for a, b, k in report[:15]))
     med = float(np.median([r[0] for r in report])), float(np.median([r[1] for r in report]))
     p95 = float(np.percentile([r[0] for r in report], 95)), float(np.percentile([r[1] for r in report], 95))
-    print('full net [2,2,1025,256]: loss %.8f (fp64 oracle %.8f); median rel-L2 gpu %.3e cpu32 %.3e; p95 gpu %.3e cpu32 %.3e'
+    print('mfma_mode %d, ' % mode + 'full net [2,2,1025,256]: loss %.8f (fp64 oracle %.8f); median rel-L2 gpu %.3e cpu32 %.3e; p95 gpu %.3e cpu32 %.3e'
           % (loss, loss64, med[0], med[1], p95[0], p95[1]))
     assert not bad, '\n'.join(bad)
     assert med[0] < max(3 * med[1], 1e-3) and p95[0] < max(3 * p95[1], 1e-2)
@@ -172,15 +187,10 @@ def test_full_net_train_step(vr, full):
         if k.endswith('running_mean') or k.endswith('running_var'):
             scale = float(sd64[k].abs().max()) + 1e-6
             assert float((state[k].double() - sd64[k]).abs().max()) < 1e-4 * scale, k
-    sdm = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
-    want_mask = cascaded_net.forward(X.double(), sdm, n_fft=N_FFT, training=True, update_running=False,
-                                     dropout={k: v.double() for k, v in masks.items()})
-    # train-mode BatchNorm over a batch of 2 amplifies fp32 rounding: the bar is the fp32 CPU oracle's own deviation
-    mask32 = cascaded_net.forward(X, weights.clone_state_dict(sd), n_fft=N_FFT, training=True, update_running=False, dropout=masks)
-    e32 = float((mask32.double() - want_mask).abs().max())
     e_gpu = float((mask.cpu().double() - want_mask).abs().max())
-    print('train-mode mask max-abs vs fp64 oracle: gpu %.3e, cpu fp32 oracle %.3e' % (e_gpu, e32))
+    print('mfma_mode %d: train-mode mask max-abs vs fp64 oracle: gpu %.3e, cpu fp32 oracle %.3e' % (mode, e_gpu, e32))
     assert e_gpu < max(1e-4, 3 * e32)
+
 
 
 # ---- small net: fixtures generated from the reference itself ---------------------------------------------------

@@ -156,6 +156,42 @@ def test_conv_winograd_vs_torch(vr, small, case):
     assert abs(rel - direct) < 1e-4
 
 
+SPLIT_CASES = [(3, 64, 128, 256, 64), (3, 61, 128, 256, 64), (3, 128, 64, 256, 128)]      # big enough for the 64-cout Winograd variant
+
+
+@pytest.mark.parametrize('case', SPLIT_CASES, ids=str)
+def test_conv_winograd_split_bf16_mode_is_fp32_exact(vr, small, case):
+    """mfma_mode 2 (fp32 products as six bf16 products of three-way split operands, fp32 accumulation) against an fp64
+    reference: its error must be the fp32-MFMA kernel's error (bar: <= 1.5x + 1e-7 of the output scale in max and in rms,
+    measured 0.9-1.1x), three orders below the bf16-operand mode; and it must differ from mode 0 in the last bits (= the
+    split kernel really ran)."""
+    N, Cin, H, W, Cout = case
+    model = small[0]
+    nat = vr.native
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g) * torch.exp(torch.randn(N, Cin, 1, 1, generator=g))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    want = F.conv2d(x.double(), w.double(), None, 1, 1).numpy()
+    scale = float(np.abs(want).max())
+    got = {}
+    try:
+        for mode in (0, 2):
+            model.set_option('mfma_mode', mode)
+            out = np.empty(want.shape, np.float32)
+            nat.check(nat.lib().vr_debug_conv2d(model._handle.h, nat.np_ptr(x.numpy()), N, Cin, H, W, nat.np_ptr(w.numpy()), Cout, 3, 1, 1, 1,
+                                                2, None, ctypes.c_float(1.0), None, nat.np_ptr(out), None))
+            got[mode] = out
+    finally:
+        model.set_option('mfma_mode', 0)
+    e0, e2 = np.abs(got[0] - want), np.abs(got[2] - want)
+    print('split mode: max %.2e rms %.2e   fp32 MFMA: max %.2e rms %.2e   (of the output scale)'
+          % (e2.max() / scale, np.sqrt((e2 ** 2).mean()) / scale, e0.max() / scale, np.sqrt((e0 ** 2).mean()) / scale))
+    assert not np.array_equal(got[0], got[2]), 'mode 2 fell back to the fp32 kernel'
+    assert e2.max() <= 1.5 * e0.max() + 1e-7 * scale
+    assert np.sqrt((e2 ** 2).mean()) <= 1.5 * np.sqrt((e0 ** 2).mean()) + 1e-7 * scale
+    assert e2.max() < 5e-6 * scale
+
+
 def test_forward_taps_small_net(vr, small):
     """Every recorded intermediate of the small net vs the oracle's (localises a broken layer)."""
     model, sd, n_fft = small
@@ -263,6 +299,24 @@ def test_predict_mask_full_net(full):
     assert got.shape == (2, 2, 1025, 128)
     assert float(diff.max()) < 1e-4 and float(diff.mean()) < 1e-5
     assert float(want.std()) > 0.02
+
+
+def test_predict_mask_full_net_split_bf16_mode(full):
+    """The same configuration with mfma_mode 2: the SAME bars against the oracle, and agreement with mode 0 at rounding level."""
+    model, sd = full
+    x = torch.rand(2, 2, 1025, 256, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        want = cascaded_net.predict_mask(x, sd)
+    ref = model.predict_mask(x.to('cuda:0')).cpu()
+    try:
+        model.set_option('mfma_mode', 2)
+        got = model.predict_mask(x.to('cuda:0')).cpu()
+    finally:
+        model.set_option('mfma_mode', 0)
+    diff = (got - want).abs()
+    print('full net, split mode: max-abs %.3e mean-abs %.3e; vs mode 0: %.3e' % (float(diff.max()), float(diff.mean()), float((got - ref).abs().max())))
+    assert float(diff.max()) < 1e-4 and float(diff.mean()) < 1e-5
+    assert not torch.equal(got, ref) and float((got - ref).abs().max()) < 2e-5
 
 
 def test_batch_independence_full_net(full):

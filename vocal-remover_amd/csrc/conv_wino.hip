@@ -22,8 +22,7 @@
 // is ~1e-6 relative (tests/test_gpu_parity.py::test_conv_winograd_vs_direct).
 #include <cstdlib>
 
-#include "conv_stage.h"
-#include "lds_dma.h"
+#include "conv_wino_epi.h"
 
 namespace vr {
 
@@ -41,7 +40,7 @@ struct WinoCfg {
     static constexpr int TH_in = TH + 2, XS0 = 3, TWq = 40, CSX = TH_in * TWq;
     static constexpr int WM = MT / 32;
     static constexpr int XS = CK * CSX;                                // raw input rows (single buffer)
-    static constexpr bool X6 = MODE >= 2;
+    static constexpr bool X6 = MODE == 2;
     static constexpr int WS = X6 ? 16 * 3 * MT * 4 : 16 * CK * MT;     // U slab   [f][cl][m] floats;  X6: [f][plane][m][8 x bf16]
     static constexpr int VS = X6 ? 16 * 3 * 2 * NT * 2 : 16 * CK * NT;   // V slab   [f][cl][tile] floats;  X6: [f][plane][cg][tile][4 x bf16]
     // 32 couts per workgroup: half the MFMA work per block, so the prologue (first DMA) and the epilogue weigh
@@ -52,7 +51,7 @@ struct WinoCfg {
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
     static constexpr int NPIECE = CSX / 4, NPASS = (NPIECE + 63) / 64;
     static constexpr int NWP = WS / 4, NWPASS = NWP / 512;             // 16-B weight pieces per wave-pass
-    static constexpr int MP = 33;                                      // epilogue exchange pitch
+    static constexpr int MP = kWinoMP;                                 // epilogue exchange pitch (conv_wino_epi.h)
     static_assert(NWP % 512 == 0, "weight slab splits evenly over 8 waves");
     static_assert(16 * 32 * MP + 2 * MT <= LDS_FLOATS && LDS_BYTES <= 160 * 1024, "LDS");
 };
@@ -61,7 +60,7 @@ template <int MT, int MODE>     // separate instantiations: a run-time branch ar
                                 // 60 spilled registers
 __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
     using Cfg = WinoCfg<MT, MODE>;
-    constexpr bool BF = MODE == 1, X6 = MODE >= 2;
+    constexpr bool BF = MODE == 1, X6 = MODE == 2;
     constexpr int TH = Cfg::TH, TW = Cfg::TW, CK = Cfg::CK, NT = Cfg::NT, TWq = Cfg::TWq, CSX = Cfg::CSX, XS0 = Cfg::XS0,
                   WM = Cfg::WM, NPIECE = Cfg::NPIECE, NPASS = Cfg::NPASS, NWPASS = Cfg::NWPASS, MP = Cfg::MP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -87,7 +86,6 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
     const int hbase = h0 - 1, wal0 = w0 - 1 - XS0;
     const int nchunk = (a.Cin + CK - 1) / CK;
     const unsigned lds0 = (unsigned)(size_t)smem;
-    const int rot = a.rot ? (rr / a.nct) % nchunk : 0;             // chunk k of the loop is input-channel chunk (k + rot) mod nchunk
 
     // per-lane source coordinates of this wave's input pieces (see conv_dma.hip)
     unsigned hrow[NPASS], wcol4[NPASS];
@@ -160,9 +158,9 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
     };
     // X6 issues the input rows first: they are needed by the transform, the weights only one barrier later (split waits below)
     auto issue_chunk = [&](int kl) {
-        const int k = kl + rot < nchunk ? kl + rot : kl + rot - nchunk;
+        const int k = kl;
         if (a.dbg == 6) return;                                                      // (ablation: no DMA at all)
-        if constexpr (X6) { issue_x(k); if (!a.rot2 || kl == 0) issue_u(kl, k, 0, 1); }
+        if constexpr (X6) { issue_x(k); if (kl == 0) issue_u(kl, k, 0, 1); }     // (later chunks: between the MFMA groups)
         else { issue_u(kl, k, 0, 1); issue_x(k); }
     };
 
@@ -272,46 +270,19 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
                     for (int ni = 0; ni < 2; ++ni) {
                         const char* q = Vb + fi * 3 * 2 * NT * 8 + ni * 32 * 8;
                         vr_i32x4 p1, p2, p3;
-                        if constexpr (MODE == 3) {
-                            // hand-issued: six ds_read_b64 (256 B/clk) where the compiler pairs them into ds_read2_b64 (128 B/clk)
-                            const unsigned qa = (unsigned)(size_t)Vb, qb = qa + (unsigned)b3;
-                            constexpr int o = 0;
-                            vr_i32x2 x0, x1, y0, y1, z0, z1;
-#define VR_LDS64(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-                            if (fi == 0 && ni == 0) {
-                                VR_LDS64(x0, qa, 0); VR_LDS64(x1, qa, NT * 8); VR_LDS64(y0, qa, 2 * NT * 8); VR_LDS64(y1, qa, 3 * NT * 8);
-                                VR_LDS64(z0, qb, 0); VR_LDS64(z1, qb, NT * 8);
-                            } else if (fi == 0 && ni == 1) {
-                                VR_LDS64(x0, qa, 256); VR_LDS64(x1, qa, 256 + NT * 8); VR_LDS64(y0, qa, 256 + 2 * NT * 8); VR_LDS64(y1, qa, 256 + 3 * NT * 8);
-                                VR_LDS64(z0, qb, 256); VR_LDS64(z1, qb, 256 + NT * 8);
-                            } else if (fi == 1 && ni == 0) {
-                                VR_LDS64(x0, qa, 6 * NT * 8); VR_LDS64(x1, qa, 7 * NT * 8); VR_LDS64(y0, qa, 8 * NT * 8); VR_LDS64(y1, qa, 9 * NT * 8);
-                                VR_LDS64(z0, qb, 6 * NT * 8); VR_LDS64(z1, qb, 7 * NT * 8);
-                            } else {
-                                VR_LDS64(x0, qa, 256 + 6 * NT * 8); VR_LDS64(x1, qa, 256 + 7 * NT * 8); VR_LDS64(y0, qa, 256 + 8 * NT * 8);
-                                VR_LDS64(y1, qa, 256 + 9 * NT * 8); VR_LDS64(z0, qb, 256 + 6 * NT * 8); VR_LDS64(z1, qb, 256 + 7 * NT * 8);
-                            }
-#undef VR_LDS64
-                            (void)o; (void)q;
-                            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1), "+v"(z0), "+v"(z1));
+                        {
+                            const vr_i32x2 x0 = *reinterpret_cast<const vr_i32x2*>(q), x1 = *reinterpret_cast<const vr_i32x2*>(q + NT * 8);
                             p1 = vr_i32x4{x0[0], x0[1], x1[0], x1[1]};
-                            p2 = vr_i32x4{y0[0], y0[1], y1[0], y1[1]};
-                            p3 = vr_i32x4{z0[0], z0[1], z1[0], z1[1]};
-                        } else {
-                            {
-                                const vr_i32x2 x0 = *reinterpret_cast<const vr_i32x2*>(q), x1 = *reinterpret_cast<const vr_i32x2*>(q + NT * 8);
-                                p1 = vr_i32x4{x0[0], x0[1], x1[0], x1[1]};
-                            }
-                            {
-                                const char* q2 = q + 2 * NT * 8;
-                                const vr_i32x2 x0 = *reinterpret_cast<const vr_i32x2*>(q2), x1 = *reinterpret_cast<const vr_i32x2*>(q2 + NT * 8);
-                                p2 = vr_i32x4{x0[0], x0[1], x1[0], x1[1]};
-                            }
-                            {
-                                const char* q3 = q + b3;
-                                const vr_i32x2 x0 = *reinterpret_cast<const vr_i32x2*>(q3), x1 = *reinterpret_cast<const vr_i32x2*>(q3 + NT * 8);
-                                p3 = vr_i32x4{x0[0], x0[1], x1[0], x1[1]};
-                            }
+                        }
+                        {
+                            const char* q2 = q + 2 * NT * 8;
+                            const vr_i32x2 x0 = *reinterpret_cast<const vr_i32x2*>(q2), x1 = *reinterpret_cast<const vr_i32x2*>(q2 + NT * 8);
+                            p2 = vr_i32x4{x0[0], x0[1], x1[0], x1[1]};
+                        }
+                        {
+                            const char* q3 = q + b3;
+                            const vr_i32x2 x0 = *reinterpret_cast<const vr_i32x2*>(q3), x1 = *reinterpret_cast<const vr_i32x2*>(q3 + NT * 8);
+                            p3 = vr_i32x4{x0[0], x0[1], x1[0], x1[1]};
                         }
                         const vr_bf16x8 B1 = __builtin_bit_cast(vr_bf16x8, p1), B2 = __builtin_bit_cast(vr_bf16x8, p2),
                                         B3 = __builtin_bit_cast(vr_bf16x8, p3);
@@ -321,12 +292,9 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
                         for (int mi = 0; mi < WM; ++mi) acc[fi][mi][ni] = mfma_bf16x16(A12[mi], B2, acc[fi][mi][ni]);
 #pragma unroll
                         for (int mi = 0; mi < WM; ++mi) acc[fi][mi][ni] = mfma_bf16x16(A13[mi], B3, acc[fi][mi][ni]);
-                        // (experiment, ConvArgs::rot2: the weight pieces of chunk k+1 are issued between the MFMA groups, not in
-                        // one burst of 8 waves x NWPASS at the top of the phase)
-                        if (a.rot2 && k + 1 < nchunk && a.dbg != 6) {
-                            const int kn = k + 1 + rot < nchunk ? k + 1 + rot : k + 1 + rot - nchunk;
-                            issue_u(k + 1, kn, fi * 2 + ni, 4);
-                        }
+                        // the weight pieces of chunk k+1 go out between the MFMA groups: one burst of 8 waves x NWPASS DMA
+                        // instructions at the top of the phase stalls it (measured: -7 % kernel time this way)
+                        if (k + 1 < nchunk && a.dbg != 6) issue_u(k + 1, k + 1, fi * 2 + ni, 4);
                     }
                 }
             }
@@ -401,92 +369,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
     }
 
     // ---------------- epilogue: gather the 16 frequencies per (cout, tile) through LDS, A^T M A ------------
-    if (a.dbg == 4) return;                                            // (ablation: no epilogue, no stores)
-    float* Mx = smem;                                                  // [16][32][MP]
-    float* stat = smem + 16 * 32 * MP;                                 // [MT][2] BatchNorm partial sums (training)
-    if (a.part && tid < 2 * MT) stat[tid] = 0.f;                       // (ordered by the first pass's barriers)
-#pragma unroll
-    for (int mi = 0; mi < WM; ++mi) {
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            if (mi + ni > 0) lds_barrier();                            // previous pass has been read
-#pragma unroll
-            for (int fi = 0; fi < 2; ++fi)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int col = (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                    Mx[((2 * wave + fi) * 32 + col) * MP + l31] = acc[fi][mi][ni][r];
-                }
-            lds_barrier();
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int p = tid + 512 * j;
-                const int col = p >> 5, tl = p & 31;
-                float m[16];
-#pragma unroll
-                for (int f = 0; f < 16; ++f) m[f] = Mx[(f * 32 + col) * MP + tl];
-                float s0[4], s1[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    s0[c] = m[c] + m[4 + c] + m[8 + c];
-                    s1[c] = m[4 + c] - m[8 + c] - m[12 + c];
-                }
-                float y[2][2];
-                y[0][0] = s0[0] + s0[1] + s0[2];
-                y[0][1] = s0[1] - s0[2] - s0[3];
-                y[1][0] = s1[0] + s1[1] + s1[2];
-                y[1][1] = s1[1] - s1[2] - s1[3];
-                const int co = co0 + mi * 32 + col;
-                const int T = ni * 32 + tl;
-                const int ho = h0 + 2 * (T >> 4), wo = w0 + 2 * (T & 15);
-                const int cc = co < a.Cout ? co : a.Cout - 1;
-                const float b = a.bias ? a.bias[cc] : 0.f;
-                float esc = 1.f, esh = 0.f, eslope = 1.f;
-                if (a.epi) { esc = a.epi[2 * cc]; esh = a.epi[2 * cc + 1]; eslope = a.epi_slope; }
-                // destination segment of this cout (the data gradient of a virtual concat has up to three)
-                const int seg = (co >= a.d1) + (co >= a.d2);
-                const int cod = co - (seg == 0 ? 0 : (seg == 1 ? a.d1 : a.d2));
-                float* dp = seg == 0 ? a.dst[0].p : (seg == 1 ? a.dst[1].p : a.dst[2].p);
-                const long long dN = seg == 0 ? a.dst[0].sN : (seg == 1 ? a.dst[1].sN : a.dst[2].sN);
-                const long long dC = seg == 0 ? a.dst[0].sC : (seg == 1 ? a.dst[1].sC : a.dst[2].sC);
-                const long long dH = seg == 0 ? a.dst[0].sH : (seg == 1 ? a.dst[1].sH : a.dst[2].sH);
-                const int dacc = seg == 0 ? a.dst[0].accumulate : (seg == 1 ? a.dst[1].accumulate : a.dst[2].accumulate);
-                float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-                for (int dr = 0; dr < 2; ++dr) {
-#pragma unroll
-                    for (int dc = 0; dc < 2; ++dc) {
-                        const float v = y[dr][dc] + b;
-                        const bool in = ho + dr < a.Hout && wo + dc < a.Wout;
-                        if (in) { t1 += v; t2 = fmaf(v, v, t2); }
-                        if (in && co < a.Cout && dp) {
-                            float* q = dp + (long long)n * dN + (long long)cod * dC + (long long)(ho + dr) * dH + wo + dc;
-                            const float o = act_apply(fmaf(v, esc, esh), eslope);
-                            *q = dacc ? *q + o : o;
-                        }
-                    }
-                }
-                if (a.part) {                                           // sum over the 32 tiles of this half-wave
-#pragma unroll
-                    for (int off = 16; off >= 1; off >>= 1) {
-                        t1 += __shfl_xor(t1, off, 64);
-                        t2 += __shfl_xor(t2, off, 64);
-                    }
-                    if (tl == 0) {                                      // (cout, pass) pairs are unique: no race
-                        stat[(mi * 32 + col) * 2 + 0] += t1;
-                        stat[(mi * 32 + col) * 2 + 1] += t2;
-                    }
-                }
-            }
-        }
-    }
-    if (a.part) {
-        lds_barrier();
-        if (tid < MT && co0 + tid < a.Cout) {
-            a.part[((long long)pt * a.Cout + co0 + tid) * 2 + 0] = stat[tid * 2 + 0];
-            a.part[((long long)pt * a.Cout + co0 + tid) * 2 + 1] = stat[tid * 2 + 1];
-        }
-    }
+    wino_epilogue<MT>(a, acc, smem, tid, wave, khalf, l31, n, h0, w0, co0, pt);
 }
 
 // U = G g G^T per (cin, cout):  w [Cin][9][CoutPad]  ->  u [Cin][16][CoutPad]
@@ -615,17 +498,12 @@ void wino_fill_tiling(ConvArgs& a, int MT) {
     a.nct = a.CoutPad / MT;
 }
 
-void wino_launch_conv(const ConvArgs& a_in, int MT, hipStream_t st) {
-    static const int rot = getenv("VR_WINO_ROT") ? atoi(getenv("VR_WINO_ROT")) : 0;
-    ConvArgs a = a_in;
-    a.rot = rot;
-    static const int rot2 = getenv("VR_X6_ILV") ? atoi(getenv("VR_X6_ILV")) : 0;
-    a.rot2 = rot2;
-    static const int x6_min_mt = getenv("VR_X6_MIN_MT") ? atoi(getenv("VR_X6_MIN_MT")) : 32;    // (experiments: 64 keeps the 32-cout variant on fp32 MFMAs)
-    static const int x6_vol = getenv("VR_X6_VOL") ? atoi(getenv("VR_X6_VOL")) : 0;
+void wino_launch_conv(const ConvArgs& a, int MT, hipStream_t st) {
+    // mode 2 on the 64-cout variant only: the 32-cout one would lose its second workgroup per CU to the bf16 planes (93 KB
+    // of LDS) and measured 1.35x SLOWER than its fp32 self (VR_X6_MIN_MT=32 runs it)
+    static const int x6_min_mt = getenv("VR_X6_MIN_MT") ? atoi(getenv("VR_X6_MIN_MT")) : 64;
     if (a.bf16 == 2 && a.wino6 && MT >= x6_min_mt) {
-        if (x6_vol) { if (MT == 64) wino_launch<64, 3>(a, st); else wino_launch<32, 3>(a, st); }
-        else { if (MT == 64) wino_launch<64, 2>(a, st); else wino_launch<32, 2>(a, st); }
+        if (MT == 64) wino_launch<64, 2>(a, st); else wino_launch<32, 2>(a, st);
     } else if (a.bf16 == 1) {
         if (MT == 64) wino_launch<64, 1>(a, st); else wino_launch<32, 1>(a, st);
     } else {

@@ -127,9 +127,6 @@ struct ConvArgs {
     int pad_h, pad_w;
     int tiles_w, tiles_h, npt, nct;
     int dbg;                   // perf experiments only (VR_CONV_DBG): 1 = skip staging, 2 = skip MFMAs
-    int rot2;                  // conv_wino.hip experiment: weight DMA of the next chunk interleaved with the MFMA groups (mode 2)
-    int rot;                   // conv_wino.hip: 1 = every workgroup starts its input-channel loop at a different chunk (workgroups of
-                               // an XCD then fetch DIFFERENT slabs of the shared Winograd weights at any moment, not all the same lines)
     int bf16;                  // Winograd kernels only.  1: MFMA operands rounded to bf16 in registers (fp32 storage and accumulation);
                                // 2: fp32 products as six bf16 products of three-way split operands (conv_stage.h), needs wino6
     int tapmask;               // 0 = all taps; else bit t set = tap t of the 3x3 is used.  The data gradient of a
