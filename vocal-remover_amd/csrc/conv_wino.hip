@@ -51,9 +51,8 @@ struct WinoCfg {
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
     static constexpr int NPIECE = CSX / 4, NPASS = (NPIECE + 63) / 64;
     static constexpr int NWP = WS / 4, NWPASS = NWP / 512;             // 16-B weight pieces per wave-pass
-    static constexpr int MP = kWinoMP;                                 // epilogue exchange pitch (conv_wino_epi.h)
     static_assert(NWP % 512 == 0, "weight slab splits evenly over 8 waves");
-    static_assert(16 * 32 * MP + 2 * MT <= LDS_FLOATS && LDS_BYTES <= 160 * 1024, "LDS");
+    static_assert(wino_epilogue_floats(MT) <= LDS_FLOATS && LDS_BYTES <= 160 * 1024, "LDS");
 };
 
 template <int MT, int MODE>     // separate instantiations: a run-time branch around the MFMA loops costs the fp32 kernel
@@ -62,7 +61,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
     using Cfg = WinoCfg<MT, MODE>;
     constexpr bool BF = MODE == 1, X6 = MODE == 2;
     constexpr int TH = Cfg::TH, TW = Cfg::TW, CK = Cfg::CK, NT = Cfg::NT, TWq = Cfg::TWq, CSX = Cfg::CSX, XS0 = Cfg::XS0,
-                  WM = Cfg::WM, NPIECE = Cfg::NPIECE, NPASS = Cfg::NPASS, NWPASS = Cfg::NWPASS, MP = Cfg::MP;
+                  WM = Cfg::WM, NPIECE = Cfg::NPIECE, NPASS = Cfg::NPASS, NWPASS = Cfg::NWPASS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xraw = smem;
     float* WsB = smem + Cfg::XS;                       // two U buffers

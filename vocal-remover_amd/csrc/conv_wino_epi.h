@@ -7,38 +7,56 @@
 
 namespace vr {
 
-constexpr int kWinoMP = 33;                                            // exchange pitch
-__host__ __device__ constexpr int wino_epilogue_floats(int MT) { return 16 * 32 * kWinoMP + 2 * MT; }
+// Exchange buffer of one pass: [f 16][register pair 8][lane 64] x 8 bytes = 64 KB, + [MT][2] BatchNorm partial sums.
+// The 64-cout kernels own enough LDS to exchange both pixel halves of a cout half at once (2 x 64 KB): half the barriers and
+// half the serial write -> barrier -> read -> store chains.
+__host__ __device__ constexpr int wino_epilogue_passes(int MT) { return MT == 64 ? 2 : 1; }
+__host__ __device__ constexpr int wino_epilogue_floats(int MT) { return wino_epilogue_passes(MT) * 16 * 8 * 64 * 2 + 2 * MT; }
 
+// The lanes of all 8 waves own the SAME (cout, tile) pairs -- accumulator register r of lane (khalf, l31) is cout
+// (r & 3) + 8 (r >> 2) + 4 khalf, tile l31 -- for different frequencies, so the exchange is wave-to-wave at a fixed lane: every
+// wave stores its two frequencies as 8 register PAIRS per lane (ds_write_b64, lane-contiguous), and wave w reads the 16
+// frequencies of pair w (ds_read_b64) and finishes the two couts of that pair.  Stores stay coalesced over the tiles (l31).
 template <int MT>
 __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, f32x16 (&acc)[2][MT / 32][2], float* smem, int tid, int wave,
                                               int khalf, int l31, int n, int h0, int w0, int co0, int pt) {
-    constexpr int WM = MT / 32, MP = kWinoMP;
-    // ---------------- epilogue: gather the 16 frequencies per (cout, tile) through LDS, A^T M A ------------
+    constexpr int WM = MT / 32;
     if (a.dbg == 4) return;                                            // (ablation: no epilogue, no stores)
-    float* Mx = smem;                                                  // [16][32][MP]
-    float* stat = smem + 16 * 32 * MP;                                 // [MT][2] BatchNorm partial sums (training)
+    constexpr int NP = wino_epilogue_passes(MT), PASS = 16 * 8 * 64;   // float2 elements of one pass
+    vr_f32x2* Mx = reinterpret_cast<vr_f32x2*>(smem);                  // [NP][16][8][64]
+    float* stat = smem + NP * PASS * 2;                                // [MT][2] BatchNorm partial sums (training)
+    const int lane = khalf * 32 + l31;
     if (a.part && tid < 2 * MT) stat[tid] = 0.f;                       // (ordered by the first pass's barriers)
 #pragma unroll
     for (int mi = 0; mi < WM; ++mi) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-            if (mi + ni > 0) lds_barrier();                            // previous pass has been read
+            if (ni % NP == 0) {
+                if (mi + ni > 0) lds_barrier();                        // previous exchange has been read
 #pragma unroll
-            for (int fi = 0; fi < 2; ++fi)
+                for (int np = 0; np < NP; ++np)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int col = (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                    Mx[((2 * wave + fi) * 32 + col) * MP + l31] = acc[fi][mi][ni][r];
-                }
-            lds_barrier();
+                    for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+                        for (int rp = 0; rp < 8; ++rp) {
+                            vr_f32x2 v;
+                            v[0] = acc[fi][mi][ni + np][2 * rp];
+                            v[1] = acc[fi][mi][ni + np][2 * rp + 1];
+                            Mx[np * PASS + ((2 * wave + fi) * 8 + rp) * 64 + lane] = v;
+                        }
+                lds_barrier();
+            }
+            vr_f32x2 mm[16];
+#pragma unroll
+            for (int f = 0; f < 16; ++f) mm[f] = Mx[(ni % NP) * PASS + (f * 8 + wave) * 64 + lane];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int p = tid + 512 * j;
-                const int col = p >> 5, tl = p & 31;
+                const int r = 2 * wave + j;
+                const int col = (r & 3) + 8 * (r >> 2) + 4 * khalf;    // cout within the 32 of this pass
+                const int tl = l31;
                 float m[16];
 #pragma unroll
-                for (int f = 0; f < 16; ++f) m[f] = Mx[(f * 32 + col) * MP + tl];
+                for (int f = 0; f < 16; ++f) m[f] = mm[f][j];
                 float s0[4], s1[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -65,18 +83,29 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, f32x16 (&acc)[2
                 const long long dC = seg == 0 ? a.dst[0].sC : (seg == 1 ? a.dst[1].sC : a.dst[2].sC);
                 const long long dH = seg == 0 ? a.dst[0].sH : (seg == 1 ? a.dst[1].sH : a.dst[2].sH);
                 const int dacc = seg == 0 ? a.dst[0].accumulate : (seg == 1 ? a.dst[1].accumulate : a.dst[2].accumulate);
+                // 8-byte stores when the row pair (wo, wo + 1) is inside and the destination rows are 8-byte aligned (wo is even)
+                const bool al8 = ((reinterpret_cast<size_t>(dp) | (size_t)(dN * 4) | (size_t)(dC * 4) | (size_t)(dH * 4)) & 7) == 0;
+                const bool in_c0 = wo < a.Wout, in_c1 = wo + 1 < a.Wout;
+                float* qrow = dp + (long long)n * dN + (long long)cod * dC + (long long)ho * dH + wo;
                 float t1 = 0.f, t2 = 0.f;
 #pragma unroll
                 for (int dr = 0; dr < 2; ++dr) {
-#pragma unroll
-                    for (int dc = 0; dc < 2; ++dc) {
-                        const float v = y[dr][dc] + b;
-                        const bool in = ho + dr < a.Hout && wo + dc < a.Wout;
-                        if (in) { t1 += v; t2 = fmaf(v, v, t2); }
-                        if (in && co < a.Cout && dp) {
-                            float* q = dp + (long long)n * dN + (long long)cod * dC + (long long)(ho + dr) * dH + wo + dc;
-                            const float o = act_apply(fmaf(v, esc, esh), eslope);
-                            *q = dacc ? *q + o : o;
+                    const bool in_r = ho + dr < a.Hout;
+                    const float v0 = y[dr][0] + b, v1 = y[dr][1] + b;
+                    if (in_r && in_c0) { t1 += v0; t2 = fmaf(v0, v0, t2); }
+                    if (in_r && in_c1) { t1 += v1; t2 = fmaf(v1, v1, t2); }
+                    if (in_r && co < a.Cout && dp) {
+                        float* q = qrow + (long long)dr * dH;
+                        float o0 = act_apply(fmaf(v0, esc, esh), eslope), o1 = act_apply(fmaf(v1, esc, esh), eslope);
+                        if (al8 && in_c1) {
+                            vr_f32x2* q2 = reinterpret_cast<vr_f32x2*>(q);
+                            vr_f32x2 o;
+                            o[0] = o0; o[1] = o1;
+                            if (dacc) { const vr_f32x2 old = *q2; o[0] += old[0]; o[1] += old[1]; }
+                            *q2 = o;
+                        } else {
+                            if (in_c0) q[0] = dacc ? q[0] + o0 : o0;
+                            if (in_c1) q[1] = dacc ? q[1] + o1 : o1;
                         }
                     }
                 }

@@ -358,25 +358,28 @@ void Model::refresh_wino(bool with_dgrad) {
     for (Conv* L : wino_list) launch_wino_weights(L->w->dev, L->wino, L->Cin, L->CoutPad, stream);
     auto cin_pad = [](const Conv* L) { return (L->Cin + 31) / 32 * 32; };
     if (mfma_mode == 2) {
+        // bf16-plane copies for the launches that can take the split kernel: the 64-cout Winograd variant only (conv_wino.hip)
+        auto fwd6 = [](const Conv* L) { return L->CoutPad % 64 == 0; };
+        auto bwd6 = [&](const Conv* L) { return cin_pad(L) % 64 == 0; };
         if (!wino6_arena) {
             size_t total = 0;
-            for (Conv* L : wino_list) total += wino_weights6_bytes(L->Cin, L->CoutPad);
-            VR_HIP(hipMalloc(reinterpret_cast<void**>(&wino6_arena), total));
+            for (Conv* L : wino_list) if (fwd6(L)) total += wino_weights6_bytes(L->Cin, L->CoutPad);
+            VR_HIP(hipMalloc(reinterpret_cast<void**>(&wino6_arena), total ? total : 16));
             size_t off = 0;
-            for (Conv* L : wino_list) { L->wino6 = wino6_arena + off; off += wino_weights6_bytes(L->Cin, L->CoutPad); }
+            for (Conv* L : wino_list) if (fwd6(L)) { L->wino6 = wino6_arena + off; off += wino_weights6_bytes(L->Cin, L->CoutPad); }
         }
-        for (Conv* L : wino_list) launch_wino_weights6(L->w->dev, L->wino6, L->Cin, L->CoutPad, stream);
+        for (Conv* L : wino_list) if (fwd6(L)) launch_wino_weights6(L->w->dev, L->wino6, L->Cin, L->CoutPad, stream);
         if (with_dgrad) {
             if (!winot6_arena) {
                 size_t total = 0;
-                for (Conv* L : wino_list) total += wino_weights6_bytes(L->Cout, cin_pad(L));
-                VR_HIP(hipMalloc(reinterpret_cast<void**>(&winot6_arena), total));
+                for (Conv* L : wino_list) if (bwd6(L)) total += wino_weights6_bytes(L->Cout, cin_pad(L));
+                VR_HIP(hipMalloc(reinterpret_cast<void**>(&winot6_arena), total ? total : 16));
                 size_t off = 0;
-                for (Conv* L : wino_list) { winot6_of[L->w] = winot6_arena + off; off += wino_weights6_bytes(L->Cout, cin_pad(L)); }
+                for (Conv* L : wino_list) if (bwd6(L)) { winot6_of[L->w] = winot6_arena + off; off += wino_weights6_bytes(L->Cout, cin_pad(L)); }
             }
             for (Conv* L : wino_list) {
                 auto it = wt_of.find(L->w);
-                if (it != wt_of.end()) launch_wino_weights6(it->second, winot6_of[L->w], L->Cout, cin_pad(L), stream);
+                if (bwd6(L) && it != wt_of.end()) launch_wino_weights6(it->second, winot6_of[L->w], L->Cout, cin_pad(L), stream);
             }
         }
     }
