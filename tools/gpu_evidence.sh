@@ -1,27 +1,29 @@
 #!/bin/bash
-# round-2 final evidence: full GPU suite, the default bench line, single-stream kernel traces + PMC passes (infer, train)
+# Round evidence on one MI355X (gpurun -- 'bash tools/gpu_evidence.sh'): the full GPU suite, the default bench line, and the
+# single-stream kernel traces + PMC passes (inference, train step) that profiles/ and bench.py's roofline.traffic cite.
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/j10; mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=6 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
-tail -14 $O/pytest.log; grep -n "bf16 MFMA mode" $O/pytest.log | head -2
-timeout 600 python bench.py > $O/bench_all.json 2> $O/bench_all.err; echo "bench rc=$?"
+O=gpurun_out/evidence; mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=6 -s > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+grep -n "passed\|failed\|error\|rc=" $O/pytest.log | tail -4
+timeout 900 python bench.py > $O/bench_all.json 2> $O/bench_all.err; echo "bench rc=$?"
 python - <<'PY'
 import json
-j=json.load(open('gpurun_out/j10/bench_all.json'))
+j=json.load(open('gpurun_out/evidence/bench_all.json'))
 print('infer', j['value'], j['ms_per_step'], j['roofline']['frac'], 'pcie', j['config'].get('pcie_inclusive_frames_per_sec'))
 print('tta', j['tta']['value'], j['tta']['ms_per_step'], j['tta']['roofline']['frac'])
 print('train', j['train']['value'], j['train']['ms_per_step'], j['train']['roofline']['frac'])
 print('train_bf16', j['train_bf16']['value'], j['train_bf16']['ms_per_step'])
+print('split_bf16', j['split_bf16']['infer'], j['split_bf16']['train'])
 print('cpu', j['cpu_baseline']['value'], j['train']['cpu_baseline']['value'])
 PY
 export VR_NO_SIDE_STREAM=1 VR_NO_SPLIT_BATCH=1
 for m in train infer; do
   timeout 400 rocprofv3 --kernel-trace --stats -d $O/kt_$m -o r -- python bench.py --mode $m --steps 2 --warmup 1 --no-cpu-baseline > $O/kt_$m.log 2>&1
-  python tools/rocpd_summary.py $(ls $O/kt_$m/*.db | head -1) $O/r02_${m}_kernel_trace_final.md > /dev/null
+  python tools/rocpd_summary.py $(ls $O/kt_$m/*.db | head -1) $O/${m}_kernel_trace.md > /dev/null
   timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_f_$m -o r -- python bench.py --mode $m --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc_f_$m.log 2>&1
   timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_w_$m -o r -- python bench.py --mode $m --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc_w_$m.log 2>&1
-  python tools/pmc_summary.py $(ls $O/pmc_f_$m/*.db | head -1) $(ls $O/pmc_w_$m/*.db | head -1) 2 $O/r02_${m}_pmc.json $m > $O/r02_${m}_pmc.md
+  python tools/pmc_summary.py $(ls $O/pmc_f_$m/*.db | head -1) $(ls $O/pmc_w_$m/*.db | head -1) 2 $O/${m}_pmc.json $m > $O/${m}_pmc.md
 done
-find $O -name "*.db" -size +4M -delete
-head -12 $O/r02_train_kernel_trace_final.md; tail -1 $O/r02_train_kernel_trace_final.md; head -3 $O/r02_train_pmc.md; head -3 $O/r02_infer_pmc.md
+find $O -name "*.db" -delete
+head -12 $O/train_kernel_trace.md; tail -1 $O/train_kernel_trace.md; head -3 $O/train_pmc.md; head -3 $O/infer_pmc.md
