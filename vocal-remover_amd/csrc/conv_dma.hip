@@ -405,8 +405,12 @@ bool dma_pick(const ConvArgs& a, const ConvShape& s, DmaTile* t) {
     if ((long long)a.Cin * s.KS * s.KS * a.CoutPad * 4 >= 0x7FFFFFF0LL) return false;
     if (a.tapmask && (a.Wout < 32 || dil || s.KS != 3 || s.stride != 1)) return false;
     if (a.Wout < 32 || dil) {
-        // 1/16-resolution layers: 16x16 pixel tiles, 32 couts per workgroup (the grids are small)
+        // 1/16-resolution layers: 16x16 pixel tiles, 32 couts per workgroup (the grids are small); 8x16 tiles when even
+        // that leaves most of the 256 CUs without a second workgroup
         t->TW = 16; t->TH = 16; t->MT = 32;
+        static const int min16 = getenv("VR_DMA_MIN16") ? atoi(getenv("VR_DMA_MIN16")) : 800;     // (measured: conv time of the step -2.8 %)
+        const long long wgs = (long long)a.N * ((a.Hout + 15) / 16) * ((a.Wout + 15) / 16) * (a.CoutPad / 32);
+        if (wgs < min16) t->TH = 8;
         return true;
     }
     int MT = (a.CoutPad % 128 == 0) ? 128 : ((a.CoutPad % 64 == 0) ? 64 : 32);
@@ -437,7 +441,14 @@ void dma_fill_tiling(ConvArgs& a, const DmaTile& t) {
 
 void dma_launch_conv(const ConvArgs& a, const ConvShape& s, const DmaTile& t, hipStream_t st) {
     const int MT = t.MT, TH = t.TH;
-    if (t.TW == 16) {
+    if (t.TW == 16 && TH == 8) {
+        if (s.KS == 1) dma_launch<1, 1, 1, 1, 32, 8, 16, 32>(a, st);
+        else if (s.stride == 2) dma_launch<3, 2, 1, 1, 32, 8, 16, 4>(a, st);
+        else if (s.dil_h == 1) dma_launch<3, 1, 1, 1, 32, 8, 16, 8>(a, st);
+        else if (s.dil_h == 4) dma_launch<3, 1, 4, 2, 32, 8, 16, 4>(a, st);
+        else if (s.dil_h == 8) dma_launch<3, 1, 8, 4, 32, 8, 16, 4>(a, st);
+        else dma_launch<3, 1, 12, 6, 32, 8, 16, 4>(a, st);
+    } else if (t.TW == 16) {
         if (s.KS == 1) dma_launch<1, 1, 1, 1, 32, 16, 16, 32>(a, st);
         else if (s.stride == 2) dma_launch<3, 2, 1, 1, 32, 16, 16, 4>(a, st);
         else if (s.dil_h == 1) dma_launch<3, 1, 1, 1, 32, 16, 16, 8>(a, st);
