@@ -477,7 +477,6 @@ bool wino_pick(const ConvArgs& a, const ConvShape& s, int* MT_out) {
         if ((long long)c.H * (c.sH > 0 ? c.sH : 1) * 4 >= 0x7FFFFFF0LL) return false;
     }
     if ((long long)a.Cin * 16 * a.CoutPad * 4 >= 0x7FFFFFF0LL) return false;
-    if (a.bf16 == 2 && !a.wino6) return false;
     const long long tiles = (long long)a.N * ((a.Hout + 7) / 8) * ((a.Wout + 31) / 32);
     int MT = (a.CoutPad % 64 == 0) ? 64 : 32;
     static const int min64 = getenv("VR_WINO_MIN64") ? atoi(getenv("VR_WINO_MIN64")) : 384;

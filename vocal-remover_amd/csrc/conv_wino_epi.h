@@ -8,9 +8,9 @@
 namespace vr {
 
 // Exchange buffer of one pass: [f 16][register pair 8][lane 64] x 8 bytes = 64 KB, + [MT][2] BatchNorm partial sums.
-// The 64-cout kernels own enough LDS to exchange both pixel halves of a cout half at once (2 x 64 KB): half the barriers and
-// half the serial write -> barrier -> read -> store chains.
-__host__ __device__ constexpr int wino_epilogue_passes(int MT) { return MT == 64 ? 2 : 1; }
+// (Exchanging both pixel halves of a cout half per barrier -- 2 x 64 KB, possible in the 64-cout kernels -- was measured: no
+// gain for the fp32 kernel, and the split-bf16 kernel's main loop came out 6 % slower from the changed register allocation.)
+__host__ __device__ constexpr int wino_epilogue_passes(int) { return 1; }
 __host__ __device__ constexpr int wino_epilogue_floats(int MT) { return wino_epilogue_passes(MT) * 16 * 8 * 64 * 2 + 2 * MT; }
 
 // The lanes of all 8 waves own the SAME (cout, tile) pairs -- accumulator register r of lane (khalf, l31) is cout
