@@ -479,7 +479,10 @@ bool wino_pick(const ConvArgs& a, const ConvShape& s, int* MT_out) {
     if ((long long)a.Cin * 16 * a.CoutPad * 4 >= 0x7FFFFFF0LL) return false;
     const long long tiles = (long long)a.N * ((a.Hout + 7) / 8) * ((a.Wout + 31) / 32);
     int MT = (a.CoutPad % 64 == 0) ? 64 : 32;
-    static const int min64 = getenv("VR_WINO_MIN64") ? atoi(getenv("VR_WINO_MIN64")) : 384;
+    // below this many 64-cout workgroups the 32-cout variant (twice the workgroups, two per CU) fills the 256 CUs better:
+    // 528 = 2.06 rounds of 256 was measured 8-10 % slower than the 32-cout form; the split-bf16 64-cout kernel keeps its edge
+    static const int min64_env = getenv("VR_WINO_MIN64") ? atoi(getenv("VR_WINO_MIN64")) : 0;
+    const int min64 = min64_env ? min64_env : (a.bf16 == 2 && a.wino6 ? 384 : 600);
     if (MT == 64 && tiles * (a.CoutPad / 64) < min64) MT = 32;
     // 32 couts per workgroup amortise the input transform poorly: with few input channels (padded to
     // chunks of 8, no partial-chunk shortcut here) the direct LDS-DMA kernel is the faster one (measured)
