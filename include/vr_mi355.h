@@ -67,6 +67,11 @@ int vr_set_mode(vr_handle h, int training);
  * "mfma_bf16" (default 0; configs[4]): 1 = the Winograd convolutions (forward, data gradient, weight gradient) and
  * the 1x1 weight-gradient GEMM round their MFMA operands to bf16 (RNE, in registers) and run on
  * v_mfma_f32_32x32x8_bf16; accumulation, every stored tensor, the master weights and Adam stay fp32.
+ * "mfma_mode" (default 0): how the Winograd kernels multiply.  0 = v_mfma_f32_32x32x2_f32 (fp32 operands);
+ * 1 = the same as "mfma_bf16" 1;  2 = fp32 products assembled from six bf16 products of three-way split operands
+ * (x = x1 + x2 + x3 exactly, a*b = a1b1 + a2b1 + a1b2 + a2b2 + a1b3 + a3b1, fp32 accumulation) on
+ * v_mfma_f32_32x32x16_bf16 in the 64-cout forward / data-gradient kernel: error equal to mode 0's against fp64,
+ * about 3 % faster end to end.  Everything else (storage, the other kernels, the weight gradients) is unchanged.
  * "params_dirty": the parameter arena was written from outside (vr_param_arena).                              */
 int vr_set_option(vr_handle h, const char* name, int value);
 
