@@ -54,8 +54,17 @@ struct DmaCfg {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
+// Waves per SIMD the register allocation must leave room for: the accumulators need (MT/32) x (pixel groups per wave) x 16
+// registers; without a bound hipcc spends 200+ registers on these kernels (one or two workgroups per CU) although their LDS
+// footprint allows three to seven -- and the LDS-DMA latency is hidden by other resident workgroups, not inside a wave.
+template <int MT, int TH, int TW>
+struct DmaOcc {
+    static constexpr int ACC = (MT / 32) * (TH * TW / 128) * 16;
+    static constexpr int value = ACC <= 32 ? 4 : (ACC <= 64 ? 3 : (ACC <= 96 ? 2 : 1));
+};
+
 template <int KS, int S, int DH, int DW, int MT, int TH, int TW, int CK, bool TM = false>
-__global__ __launch_bounds__(256) void conv_dma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, (DmaOcc<MT, TH, TW>::value)) void conv_dma_kernel(const ConvArgs a) {
     using Cfg = DmaCfg<KS, S, DH, DW, MT, TH, TW, CK>;
     constexpr int KK = Cfg::KK, WM = Cfg::WM, WN = Cfg::WN, TWq = Cfg::TWq, TWn = Cfg::TWn, CSX = Cfg::CSX,
                   XS0 = Cfg::XS0, NPIECE = Cfg::NPIECE, NPASS = Cfg::NPASS, NWP = Cfg::NWP, NWPASS = Cfg::NWPASS,
@@ -382,6 +391,215 @@ static void dma_launch(const ConvArgs& a, hipStream_t st) {
 static bool src_plain(const ConvSrc& s) {
     return !s.aff0 && !s.aff1 && !s.post && !s.up && !s.zins && s.slope == 1.f;
 }
+
+// -------------------------------------------------------------------------------------------------------
+// Data gradient of a stride-2 3x3 conv, all four output-parity classes in ONE launch (train.hip: run_conv_backward).
+//   dx[2i+ph][2j+pw] = sum over the class's live taps of  w_cls[tap] * dz[i + th - 1][j + tw - 1],   th in {1} (ph = 0) or {1,2} (ph = 1)
+// Every (class, tap) pair is one of nine: the launch stages the dz tile and the nine weight slices ONCE per input-channel
+// chunk and runs nine MFMA sets into four accumulator sets -- the work of one 3x3 conv -- where the four tap-masked launches
+// (conv_dma_kernel<..., TM>) each staged the full tile and all nine slices for 1 / 2 / 2 / 4 live taps and waited on the DMA
+// 74 % of the time (profiles/r02_train_sq_pmc.md).  32 couts x (8 x 32) dz pixels per workgroup = 16 x 64 output pixels;
+// the two column parities of an output row leave as one 8-byte read-modify-write (the destinations accumulate).
+template <int CK>
+__global__ __launch_bounds__(256, 3) void conv_dma_s2d_kernel(const ConvArgs a) {
+    constexpr int MT = 32, TH = 8, TW = 32;
+    using Cfg = DmaCfg<3, 1, 1, 1, MT, TH, TW, CK>;
+    constexpr int WN = Cfg::WN, TWq = Cfg::TWq, TWn = Cfg::TWn, CSX = Cfg::CSX, XS0 = Cfg::XS0, NPIECE = Cfg::NPIECE,
+                  NPASS = Cfg::NPASS, NWP = Cfg::NWP, NWPASS = Cfg::NWPASS, CPW = Cfg::CPW;
+    // the nine (class, tap) pairs: class = ph * 2 + pw, tap = th * 3 + tw
+    constexpr int PCLS[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
+    constexpr int PTAP[9] = {4, 4, 5, 4, 7, 4, 5, 7, 8};
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int rr = id >> 3;
+    const int ct = rr % a.nct;
+    const int pt = (rr / a.nct) * 8 + xcd;
+    if (pt >= a.npt) return;
+    const int tiles_per_img = a.tiles_h * a.tiles_w;
+    const int n = pt / tiles_per_img;
+    const int trem = pt - n * tiles_per_img;
+    const int h0 = (trem / a.tiles_w) * TH;
+    const int w0 = (trem % a.tiles_w) * TW;
+    const int co0 = ct * MT;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hbase = h0 - 1, wal0 = w0 - 1 - XS0;
+    const int nchunk = a.Cin / CK;                      // (Cin % CK == 0: eligibility)
+    const unsigned lds0 = (unsigned)(size_t)smem;
+
+    unsigned hrow[NPASS], wcol4[NPASS];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int q = p * 64 + lane;
+        const int hh = q / (TWq / 4), j = q % (TWq / 4);
+        const int hi = hbase + hh, wi = wal0 + 4 * j;
+        const bool ok = q < NPIECE && 4 * j < TWn && hi >= 0 && hi < a.Hin && wi >= 0 && wi + 3 < a.Win;
+        hrow[p] = ok ? (unsigned)hi : 0u;
+        wcol4[p] = ok ? (unsigned)(wi * 4) : 0x80000000u;
+    }
+    // weight pieces: LDS order [pair][cl][m], source class array PCLS[pair], w_cls[(cl * 9 + PTAP[pair]) * CoutPad + m]
+    unsigned woff[NWPASS];
+#pragma unroll
+    for (int i = 0; i < NWPASS; ++i) {
+        const int q = (wave + 4 * i) * 64 + lane;
+        const int m4 = q % (MT / 4), t2 = q / (MT / 4);
+        const int cl = t2 % CK, pr = t2 / CK;
+        int cls = 0, tap = 4;
+#pragma unroll
+        for (int e = 0; e < 9; ++e)
+            if (pr == e) { cls = PCLS[e]; tap = PTAP[e]; }
+        woff[i] = (unsigned)(((long long)cls * a.s2_cls_stride + ((long long)(cl * 9 + tap) * a.CoutPad + m4 * 4)) * 4);
+    }
+    const unsigned w_bytes = (unsigned)((3 * a.s2_cls_stride + (long long)a.Cin * 9 * a.CoutPad) * 4);
+
+    auto issue_chunk = [&](int k) {
+        const int c0 = k * CK;
+        const unsigned xs_b = lds0 + (unsigned)((k & 1) * Cfg::BUF * 4);
+        const unsigned ws_b = xs_b + Cfg::XS * 4;
+        {
+            const long long boff = (long long)c0 * 9 * a.CoutPad + co0;
+            const i32x4 wr = make_rsrc(a.w + boff, w_bytes - (unsigned)(boff * 4));
+#pragma unroll
+            for (int i = 0; i < NWPASS; ++i) {
+                const int pp = wave + 4 * i;
+                if (pp * 64 + lane < NWP) dma16(ws_b + pp * 1024, woff[i], wr);
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < CPW; ++cc) {
+            const int cl = wave + 4 * cc;
+            const int ci = c0 + cl;
+            const i32x4 xr = make_rsrc(a.src[0].p + (long long)n * a.src[0].sN + (long long)ci * a.src[0].sC, 0x7FFFFFF0u);
+            const unsigned sH4 = (unsigned)a.src[0].sH * 4u;
+            const unsigned cb = xs_b + (unsigned)(cl * CSX * 4);
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) {
+                const unsigned vo = hrow[p] * sH4 + wcol4[p];
+                if ((p + 1) * 64 <= NPIECE) dma16(cb + p * 1024, vo, xr);
+                else if (p * 64 + lane < NPIECE) dma16(cb + p * 1024, vo, xr);
+            }
+        }
+    };
+
+    const int khalf = lane >> 5, l31 = lane & 31;
+    int boff[WN];
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) {
+        const int pix = (wave * WN + ni) * 32 + l31;
+        boff[ni] = khalf * CSX + (pix / TW) * TWq + pix % TW + XS0;
+    }
+    const int aoff = khalf * MT + l31;
+    f32x16 acc[4][WN];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][ni][r] = 0.f;
+
+    issue_chunk(0);
+    dma_wait_and_barrier();
+    constexpr int NS = 9 * (CK / 2);
+    for (int k = 0; k < nchunk; ++k) {
+        if (k + 1 < nchunk) issue_chunk(k + 1);
+        const float* Xs = smem + (k & 1) * Cfg::BUF;
+        const float* Ws = Xs + Cfg::XS;
+        float av = Ws[aoff], bv[WN];
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) bv[ni] = Xs[(PTAP[0] / 3) * TWq + PTAP[0] % 3 + boff[ni]];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            float avn = 0.f, bvn[WN];
+            if (s + 1 < NS) {
+                const int pr = (s + 1) / (CK / 2), kk = (s + 1) % (CK / 2);
+                const int toff = (PTAP[pr] / 3) * TWq + PTAP[pr] % 3;
+                avn = Ws[(pr * CK + 2 * kk) * MT + aoff];
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni) bvn[ni] = Xs[2 * kk * CSX + toff + boff[ni]];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni)
+                acc[PCLS[s / (CK / 2)]][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[ni], acc[PCLS[s / (CK / 2)]][ni], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < NS) {
+                av = avn;
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni) bv[ni] = bvn[ni];
+            }
+        }
+        dma_wait_and_barrier();
+    }
+
+    // epilogue: dx[2 ho + ph][2 wo + pw] += acc[ph * 2 + pw]; the pw pair of a row is one 8-byte access when aligned
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (co >= a.Cout) continue;
+        const int seg = (co >= a.d1) + (co >= a.d2);
+        const int cod = co - (seg == 0 ? 0 : (seg == 1 ? a.d1 : a.d2));
+        float* dp = seg == 0 ? a.dst[0].p : (seg == 1 ? a.dst[1].p : a.dst[2].p);
+        if (!dp) continue;
+        const long long dN = seg == 0 ? a.dst[0].sN : (seg == 1 ? a.dst[1].sN : a.dst[2].sN);
+        const long long dC = seg == 0 ? a.dst[0].sC : (seg == 1 ? a.dst[1].sC : a.dst[2].sC);
+        const long long dH = seg == 0 ? a.dst[0].sH : (seg == 1 ? a.dst[1].sH : a.dst[2].sH);
+        const int dacc = seg == 0 ? a.dst[0].accumulate : (seg == 1 ? a.dst[1].accumulate : a.dst[2].accumulate);
+        const bool al8 = ((reinterpret_cast<size_t>(dp) | (size_t)(dN * 4) | (size_t)(dC * 4) | (size_t)(dH * 4)) & 7) == 0;
+        float* base = dp + (long long)n * dN + (long long)cod * dC;
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) {
+            const int pix = (wave * WN + ni) * 32 + l31;
+            const int ho = h0 + pix / TW, wo = w0 + pix % TW;
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                const int hf = 2 * ho + ph, wf = 2 * wo;
+                if (hf >= a.s2_H || wf >= a.s2_W) continue;
+                float* q = base + (long long)hf * dH + wf;
+                const float v0 = acc[ph * 2][ni][r], v1 = acc[ph * 2 + 1][ni][r];
+                if (al8 && wf + 1 < a.s2_W) {
+                    vr_f32x2* q2 = reinterpret_cast<vr_f32x2*>(q);
+                    vr_f32x2 o;
+                    o[0] = v0; o[1] = v1;
+                    if (dacc) { const vr_f32x2 old = *q2; o[0] += old[0]; o[1] += old[1]; }
+                    *q2 = o;
+                } else {
+                    q[0] = dacc ? q[0] + v0 : v0;
+                    if (wf + 1 < a.s2_W) q[1] = dacc ? q[1] + v1 : v1;
+                }
+            }
+        }
+    }
+}
+
+// Fused stride-2 data gradient: dz is a single plain source, weights = the four class arrays of launch_s2_class_weights.
+bool s2d_fused_eligible(const ConvArgs& a) {
+    static const int enabled = getenv("VR_S2D_FUSED") ? atoi(getenv("VR_S2D_FUSED")) : 1;
+    if (!enabled || a.nsrc != 1 || (a.Cin & 3) || a.Wout < 32 || (a.Win & 3)) return false;
+    const ConvSrc& c = a.src[0];
+    if (!src_plain(c) || c.W != a.Win) return false;
+    if ((long long)c.H * (c.sH > 0 ? c.sH : 1) * 4 >= 0x7FFFFFF0LL) return false;
+    if ((3 * a.s2_cls_stride + (long long)a.Cin * 9 * a.CoutPad) * 4 >= 0x7FFFFFF0LL) return false;
+    return true;
+}
+
+void launch_s2d_fused(const ConvArgs& a_in, hipStream_t st) {
+    ConvArgs a = a_in;
+    a.tiles_w = (a.Wout + 31) / 32;
+    a.tiles_h = (a.Hout + 7) / 8;
+    a.npt = a.N * a.tiles_h * a.tiles_w;
+    a.nct = a.CoutPad / 32;
+    using Cfg = DmaCfg<3, 1, 1, 1, 32, 8, 32, 4>;
+    auto kern = conv_dma_s2d_kernel<4>;
+    static std::atomic<unsigned long long> attr_done{0};
+    ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
+    const int groups = (a.npt + 7) / 8;
+    hipLaunchKernelGGL(kern, dim3(groups * 8 * a.nct), dim3(256), Cfg::LDS_BYTES, st, a);
+    VR_HIP(hipGetLastError());
+}
+
 
 // True when the launch can take the LDS-DMA kernel; fills the tile choice (MT, TH, TW).
 bool dma_pick(const ConvArgs& a, const ConvShape& s, DmaTile* t) {

@@ -49,6 +49,8 @@ void launch_materialize(const Tensor& x, float* out, hipStream_t st);
 struct AugDesc { float coef, coef_mix, lam; int flags; };
 void launch_augment(const float2* X, const float2* Y, const float2* Xi, const float2* Yi, const AugDesc* desc, const float* rw,
                     int B, int T, int bins, float* Xmag, float* Ymag, hipStream_t st);
+bool s2d_fused_eligible(const ConvArgs& a);                       // conv_dma.hip: stride-2 data gradient, four parity classes in one launch
+void launch_s2d_fused(const ConvArgs& a, hipStream_t st);
 void launch_s2_class_weights(const float* w, float* wc, int Cin, int Cout, int CoutPad, int CinPad, hipStream_t st);
 void launch_wino_weights(const float* w, float* u, int Cin, int CoutPad, hipStream_t st);   // U = G g G^T
 size_t wino_weights6_bytes(int Cin, int CoutPad);                                           // U as three bf16 planes (mfma_mode 2)

@@ -248,6 +248,19 @@ void Model::bwd_conv(TapeRec& r) {
             c.Hin = out.H; c.Win = out.W;
             const ConvShape cshp{3, 1, 1, 1};
             const size_t cls_stride = (size_t)L.Cout * 9 * round_up32(L.Cin);
+            // all four classes in one launch (one staging of dz and of the nine live (class, tap) weight slices per chunk)
+            {
+                ConvArgs k = c;
+                k.Hout = (f.Hin + 1) / 2; k.Wout = (f.Win + 1) / 2;
+                k.w = it->second; k.wino = nullptr; k.wino6 = nullptr;
+                k.s2_cls_stride = (long long)cls_stride; k.s2_H = f.Hin; k.s2_W = f.Win;
+                if (s2d_fused_eligible(k)) {
+                    record_begin(0, 2.0 * N * (double)f.Hout * f.Wout * (double)L.Cout * L.Cin * L.KS * L.KS);
+                    launch_s2d_fused(k, stream);
+                    record_end();
+                    return;
+                }
+            }
             const int masks[2] = {1 << 1, (1 << 1) | (1 << 2)};          // live taps along one axis: parity 0 / 1
             for (int cls = 0; cls < 4 && ok; ++cls) {
                 const int ph = cls >> 1, pw = cls & 1;

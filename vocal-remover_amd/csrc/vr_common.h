@@ -129,6 +129,8 @@ struct ConvArgs {
     int dbg;                   // perf experiments only (VR_CONV_DBG): 1 = skip staging, 2 = skip MFMAs
     int bf16;                  // Winograd kernels only.  1: MFMA operands rounded to bf16 in registers (fp32 storage and accumulation);
                                // 2: fp32 products as six bf16 products of three-way split operands (conv_stage.h), needs wino6
+    long long s2_cls_stride;   // conv_dma_s2d_kernel (fused form of the four parity classes below): floats between the class weight
+    int s2_H, s2_W;            // arrays in `w`; full-resolution output dims (the four classes interleave into them)
     int tapmask;               // 0 = all taps; else bit t set = tap t of the 3x3 is used.  The data gradient of a
                                // stride-2 conv is four stride-1 convs over dz, one per output parity (ph, pw), with
                                // 1 / 2 / 2 / 4 live taps and outputs interleaved (dst.wshift, doubled row stride):
