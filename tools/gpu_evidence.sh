@@ -25,5 +25,15 @@ for m in train infer; do
   timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_w_$m -o r -- python bench.py --mode $m --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc_w_$m.log 2>&1
   python tools/pmc_summary.py $(ls $O/pmc_f_$m/*.db | head -1) $(ls $O/pmc_w_$m/*.db | head -1) 2 $O/${m}_pmc.json $m > $O/${m}_pmc.md
 done
+# MFMA-pipe utilisation and wave states from the SQ counters, calibrated on tools/mfma_peak.hip (tools/pmc_sq_summary.py)
+C="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"
+hipcc --offload-arch=gfx950 -O3 tools/mfma_peak.hip -o /tmp/mfma_peak 2>/dev/null
+timeout 300 rocprofv3 --kernel-trace --pmc $C -d $O/sq_cal -o r -- /tmp/mfma_peak > $O/sq_cal.log 2>&1
+for m in infer train; do
+  timeout 400 rocprofv3 --kernel-trace --pmc $C -d $O/sq_$m -o r -- python bench.py --mode $m --steps 1 --warmup 0 --no-cpu-baseline > $O/sq_$m.log 2>&1
+  python tools/pmc_sq_summary.py $(ls $O/sq_$m/*.db | head -1) $(ls $O/sq_cal/*.db | head -1) $O/${m}_sq_pmc.json > $O/${m}_sq_pmc.md
+done
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 find $O -name "*.db" -delete
 head -12 $O/train_kernel_trace.md; tail -1 $O/train_kernel_trace.md; head -3 $O/train_pmc.md; head -3 $O/infer_pmc.md
+head -8 $O/train_sq_pmc.md | cut -c1-120; grep "all kernels" $O/*_sq_pmc.md
