@@ -323,6 +323,9 @@ static TileChoice pick_tile(const ConvArgs& a, const ConvShape& s) {
 }
 
 bool ws_pick(const ConvArgs& a, const ConvShape& s, int* MT_out, int* TH_out);
+bool thin16_pick(const ConvArgs& a, const ConvShape& s, int* TH);
+void thin16_fill_tiling(ConvArgs& a, int TH);
+void thin16_launch_conv(const ConvArgs& a, const ConvShape& s, int TH, hipStream_t st);
 bool wino_pick(const ConvArgs& a, const ConvShape& s, int* MT_out);
 void wino_fill_tiling(ConvArgs& a, int MT);
 void wino_launch_conv(const ConvArgs& a, int MT, hipStream_t st);
@@ -335,7 +338,8 @@ void ws_launch_conv(const ConvArgs& a, const ConvShape& s, int MT, int TH, hipSt
 
 void conv_fill_tiling(ConvArgs& a, const ConvShape& s) {
     int wmt, wth;
-    int wino_mt;
+    int wino_mt, thin_th;
+    if (thin16_pick(a, s, &thin_th)) { thin16_fill_tiling(a, thin_th); return; }
     if (wino_pick(a, s, &wino_mt)) { wino_fill_tiling(a, wino_mt); return; }
     DmaTile dt;
     if (dma_pick(a, s, &dt)) { dma_fill_tiling(a, dt); return; }
@@ -390,7 +394,12 @@ double launch_conv(const ConvArgs& a_in, const ConvShape& s, hipStream_t st) {
     a.dbg = dbg;
     {
         int wmt, wth;
-        int wino_mt;
+        int wino_mt, thin_th;
+        if (a.nsrc >= 1 && a.nsrc <= 3 && thin16_pick(a, s, &thin_th)) {
+            thin16_fill_tiling(a, thin_th);
+            thin16_launch_conv(a, s, thin_th, st);
+            return 2.0 * a.N * (double)a.Hout * a.Wout * (double)a.Cout * a.Cin * s.KS * s.KS;
+        }
         if (a.nsrc >= 1 && a.nsrc <= 3 && wino_pick(a, s, &wino_mt)) {
             wino_fill_tiling(a, wino_mt);
             wino_launch_conv(a, wino_mt, st);

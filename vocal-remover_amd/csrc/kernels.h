@@ -49,6 +49,9 @@ void launch_materialize(const Tensor& x, float* out, hipStream_t st);
 struct AugDesc { float coef, coef_mix, lam; int flags; };
 void launch_augment(const float2* X, const float2* Y, const float2* Xi, const float2* Yi, const AugDesc* desc, const float* rw,
                     int B, int T, int bins, float* Xmag, float* Ymag, hipStream_t st);
+bool thin16_pick(const ConvArgs& a, const ConvShape& s, int* TH);  // conv_thin.hip: <= 16 couts on v_mfma_f32_16x16x4_f32
+void thin16_fill_tiling(ConvArgs& a, int TH);
+void thin16_launch_conv(const ConvArgs& a, const ConvShape& s, int TH, hipStream_t st);
 bool s2d_fused_eligible(const ConvArgs& a);                       // conv_dma.hip: stride-2 data gradient, four parity classes in one launch
 void launch_s2d_fused(const ConvArgs& a, hipStream_t st);
 void launch_s2_class_weights(const float* w, float* wc, int Cin, int Cout, int CoutPad, int CinPad, hipStream_t st);
