@@ -119,11 +119,12 @@ def cpu_baseline_train(sd, B=2):
                       '[2,1025,256] (the GPU runs batch 16), %.1f s wall' % (B, dt)}
 
 
-CONV_FAMILY_INFER = ('conv family on v_mfma_f32_32x32x2_f32: conv_wino_kernel<*> (Winograd F(2x2,3x3), the 3x3 stride-1 '
-                     'layers) + conv_dma_kernel<*> (direct implicit GEMM: stride-2, dilated, 1x1, thin layers)')
-CONV_FAMILY_TRAIN = ('conv family on v_mfma_f32_32x32x2_f32: conv_wino_kernel<*> / conv_dma_kernel<*> (forward + data '
-                     'gradients over materialised plain tensors; stride-2 data gradient = 4 tap-masked parity convs) + '
-                     'wgrad_*_kernel<*> (weight gradient, LDS-DMA loader)')
+CONV_FAMILY_INFER = ('conv family on the fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4): conv_wino_kernel<*> (Winograd F(2x2,3x3), the '
+                     '3x3 stride-1 layers) + conv_dma_kernel<*> (direct implicit GEMM: stride-2, dilated, 1x1) + conv_thin_kernel<*> '
+                     '(3x3 layers with <= 16 output channels)')
+CONV_FAMILY_TRAIN = ('conv family on the fp32 MFMA: conv_wino_kernel<*> / conv_dma_kernel<*> / conv_thin_kernel<*> (forward + data '
+                     'gradients over materialised plain tensors; stride-2 data gradient = conv_dma_s2d_kernel, the four parity '
+                     'classes in one launch) + wgrad_*_kernel<*> (weight gradient: Winograd F(3x3,2x2), LDS-DMA GEMMs)')
 
 
 def self_launch(args):

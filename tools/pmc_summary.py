@@ -7,9 +7,9 @@ import re
 import sqlite3
 import sys
 
-FAMILY = 'conv family (conv_wino + conv_dma + conv_ws + conv_mfma + wgrad)'
-KEYS = ('conv_mfma_kernel', 'conv_ws_kernel', 'conv_dma_kernel', 'conv_wino_kernel', 'wgrad_ws_kernel', 'wgrad_mfma_kernel',
-        'wgrad_wino_kernel', 'wgrad_gemm_kernel')
+FAMILY = 'conv family (conv_wino + conv_dma + conv_thin + conv_ws + conv_mfma + wgrad)'
+KEYS = ('conv_mfma_kernel', 'conv_ws_kernel', 'conv_dma_kernel', 'conv_dma_s2d_kernel', 'conv_thin_kernel', 'conv_wino_kernel',
+        'wgrad_ws_kernel', 'wgrad_mfma_kernel', 'wgrad_wino_kernel', 'wgrad_gemm_kernel')
 
 
 def load(path, counter):
