@@ -34,6 +34,8 @@ for m in infer train; do
   python tools/pmc_sq_summary.py $(ls $O/sq_$m/*.db | head -1) $(ls $O/sq_cal/*.db | head -1) $O/${m}_sq_pmc.json > $O/${m}_sq_pmc.md
 done
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+# the whole GPU suite once more with the split-bf16 multiply mode as the default of every handle (same tolerances)
+VR_MFMA_MODE=2 timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/pytest_mfma_mode2.log 2>&1; echo "pytest (VR_MFMA_MODE=2) rc=$?"; tail -1 $O/pytest_mfma_mode2.log
 find $O -name "*.db" -delete
 head -12 $O/train_kernel_trace.md; tail -1 $O/train_kernel_trace.md; head -3 $O/train_pmc.md; head -3 $O/infer_pmc.md
 head -8 $O/train_sq_pmc.md | cut -c1-120; grep "all kernels" $O/*_sq_pmc.md

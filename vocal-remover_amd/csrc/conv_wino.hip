@@ -113,9 +113,9 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
         }
     }
 
-    auto issue_u = [&](int kl, int k, int i0, int istep) {          // weight pieces i0, i0 + istep, ... of this wave
+    auto issue_u = [&](int k, int i0, int istep) {                  // weight pieces i0, i0 + istep, ... of this wave, chunk k
         const int c0 = k * CK;
-        const unsigned ws_b = lds0 + (unsigned)((Cfg::XS + (kl & 1) * Cfg::WS) * 4);
+        const unsigned ws_b = lds0 + (unsigned)((Cfg::XS + (k & 1) * Cfg::WS) * 4);
         if (a.dbg == 7) {                                                            // (ablation: no weight DMA)
         } else if constexpr (X6) {
             const long long chunk_bytes = 48LL * a.CoutPad * 16;
@@ -156,11 +156,10 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
         }
     };
     // X6 issues the input rows first: they are needed by the transform, the weights only one barrier later (split waits below)
-    auto issue_chunk = [&](int kl) {
-        const int k = kl;
+    auto issue_chunk = [&](int k) {
         if (a.dbg == 6) return;                                                      // (ablation: no DMA at all)
-        if constexpr (X6) { issue_x(k); if (kl == 0) issue_u(kl, k, 0, 1); }     // (later chunks: between the MFMA groups)
-        else { issue_u(kl, k, 0, 1); issue_x(k); }
+        if constexpr (X6) { issue_x(k); if (k == 0) issue_u(k, 0, 1); }          // (later chunks: between the MFMA groups)
+        else { issue_u(k, 0, 1); issue_x(k); }
     };
 
     // input transform of this wave's channel: lane = Winograd tile (ti = lane >> 4, tj = lane & 15)
@@ -293,7 +292,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
                         for (int mi = 0; mi < WM; ++mi) acc[fi][mi][ni] = mfma_bf16x16(A13[mi], B3, acc[fi][mi][ni]);
                         // the weight pieces of chunk k+1 go out between the MFMA groups: one burst of 8 waves x NWPASS DMA
                         // instructions at the top of the phase stalls it (measured: -7 % kernel time this way)
-                        if (k + 1 < nchunk && a.dbg != 6) issue_u(k + 1, k + 1, fi * 2 + ni, 4);
+                        if (k + 1 < nchunk && a.dbg != 6) issue_u(k + 1, fi * 2 + ni, 4);
                     }
                 }
             }
