@@ -307,6 +307,7 @@ def test_predict_mask_full_net_split_bf16_mode(full):
     x = torch.rand(2, 2, 1025, 256, generator=torch.Generator().manual_seed(2))
     with torch.no_grad():
         want = cascaded_net.predict_mask(x, sd)
+    model.set_option('mfma_mode', 0)
     ref = model.predict_mask(x.to('cuda:0')).cpu()
     try:
         model.set_option('mfma_mode', 2)
