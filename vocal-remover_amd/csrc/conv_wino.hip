@@ -23,6 +23,7 @@
 #include <cstdlib>
 
 #include "conv_wino_epi.h"
+#include "kernels.h"
 
 namespace vr {
 
@@ -371,8 +372,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const ConvArgs a) {
 }
 
 // U = G g G^T per (cin, cout):  w [Cin][9][CoutPad]  ->  u [Cin][16][CoutPad]
-__global__ void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int Cin, int CoutPad) {
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void wino_weights_elem(const float* __restrict__ w, float* __restrict__ u, int Cin, int CoutPad, long long gid) {
     if (gid >= (long long)Cin * CoutPad) return;
     const int co = (int)(gid % CoutPad);
     const int ci = (int)(gid / CoutPad);
@@ -396,6 +396,9 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, float* __restri
         o[3LL * CoutPad] = t[r][2];
     }
 }
+__global__ void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int Cin, int CoutPad) {
+    wino_weights_elem(w, u, Cin, CoutPad, (long long)blockIdx.x * blockDim.x + threadIdx.x);
+}
 
 void launch_wino_weights(const float* w, float* u, int Cin, int CoutPad, hipStream_t st) {
     const long long n = (long long)Cin * CoutPad;
@@ -404,8 +407,8 @@ void launch_wino_weights(const float* w, float* u, int Cin, int CoutPad, hipStre
 }
 
 // The same U as three bf16 planes (conv_stage.h): u6 [ceil(Cin/8)][16][3][CoutPad][8 channels], zero for channels >= Cin.
-__global__ void wino_weights6_kernel(const float* __restrict__ w, unsigned short* __restrict__ u6, int Cin, int CoutPad) {
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void wino_weights6_elem(const float* __restrict__ w, unsigned short* __restrict__ u6, int Cin, int CoutPad,
+                                                   long long gid) {
     const int cin8 = (Cin + 7) / 8 * 8;
     if (gid >= (long long)cin8 * CoutPad) return;
     const int co = (int)(gid % CoutPad);
@@ -439,6 +442,24 @@ __global__ void wino_weights6_kernel(const float* __restrict__ w, unsigned short
             o[(f * 3 + 2) * CoutPad * 8] = (unsigned short)(p3 & 0xffff);
         }
     }
+}
+__global__ void wino_weights6_kernel(const float* __restrict__ w, unsigned short* __restrict__ u6, int Cin, int CoutPad) {
+    wino_weights6_elem(w, u6, Cin, CoutPad, (long long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// Every layer of a model in one launch (the training step refreshes ~90 of these per step): blockIdx.y = descriptor
+__global__ void wino_weights_batched_kernel(const WinoWDesc* __restrict__ d, int split6) {
+    const WinoWDesc e = d[blockIdx.y];
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (split6) wino_weights6_elem(e.w, static_cast<unsigned short*>(e.u), e.Cin, e.CoutPad, gid);
+    else wino_weights_elem(e.w, static_cast<float*>(e.u), e.Cin, e.CoutPad, gid);
+}
+
+void launch_wino_weights_batched(const WinoWDesc* d_descs, int n, long long max_elems, bool split6, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(wino_weights_batched_kernel, dim3((unsigned)((max_elems + 255) / 256), (unsigned)n), dim3(256), 0, st, d_descs,
+                       split6 ? 1 : 0);
+    VR_HIP(hipGetLastError());
 }
 
 size_t wino_weights6_bytes(int Cin, int CoutPad) { return (size_t)((Cin + 7) / 8) * 48 * CoutPad * 16; }

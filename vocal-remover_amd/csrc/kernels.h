@@ -56,6 +56,8 @@ bool s2d_fused_eligible(const ConvArgs& a);                       // conv_dma.hi
 void launch_s2d_fused(const ConvArgs& a, hipStream_t st);
 void launch_s2_class_weights(const float* w, float* wc, int Cin, int Cout, int CoutPad, int CinPad, hipStream_t st);
 void launch_wino_weights(const float* w, float* u, int Cin, int CoutPad, hipStream_t st);   // U = G g G^T
+struct WinoWDesc { const float* w; void* u; int Cin, CoutPad; };                              // one layer of a batched refresh
+void launch_wino_weights_batched(const WinoWDesc* d_descs, int n, long long max_elems, bool split6, hipStream_t st);
 size_t wino_weights6_bytes(int Cin, int CoutPad);                                           // U as three bf16 planes (mfma_mode 2)
 void launch_wino_weights6(const float* w, void* u6, int Cin, int CoutPad, hipStream_t st);
 void launch_upsample2x(const Tensor& x, float* out, hipStream_t st);   // dense [N][C][2H][2W], activated

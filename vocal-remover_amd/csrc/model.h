@@ -191,6 +191,10 @@ private:
     char* winot6_arena = nullptr;
     std::map<const Param*, void*> winot6_of;
     void refresh_wino(bool with_dgrad);
+    // batched refresh: descriptor tables (host copy + device copy, re-uploaded only when a pointer changed)
+    struct WinoBatch { std::vector<WinoWDesc> host; WinoWDesc* dev = nullptr; long long max_elems = 0; };
+    WinoBatch wb_fwd, wb_bwd, wb_fwd6, wb_bwd6;
+    void run_wino_batch(WinoBatch& b, std::vector<WinoWDesc>& descs, bool split6);
     BNFoldDesc* d_fold = nullptr;
     bool affine_dirty = true;
     void fold_eval_affines();

@@ -242,7 +242,7 @@ Model::~Model() {
     hipFree(wire_buf);
     if (stream) hipStreamSynchronize(stream);
     hipFree(p_arena); hipFree(b_arena); hipFree(d_fold);
-    hipFree(ws.base); hipFree(io.base); hipFree(gs.base); hipFree(wino_arena); hipFree(winot_arena); hipFree(wino6_arena); hipFree(winot6_arena); hipFree(aug_buf);
+    hipFree(ws.base); hipFree(io.base); hipFree(gs.base); hipFree(wino_arena); hipFree(winot_arena); hipFree(wino6_arena); hipFree(winot6_arena); hipFree(wb_fwd.dev); hipFree(wb_bwd.dev); hipFree(wb_fwd6.dev); hipFree(wb_bwd6.dev); hipFree(aug_buf);
     hipFree(g_arena); hipFree(m_arena); hipFree(v_arena); hipFree(wt_arena); hipFree(d_flip); hipFree(dropout_buf);
     hipFree(plan.twiddle); hipFree(plan.window);
     for (Lane& l : lanes) {
@@ -355,7 +355,11 @@ void Model::refresh_wino(bool with_dgrad) {
         size_t off = 0;
         for (Conv* L : wino_list) { L->wino = wino_arena + off; off += (size_t)L->Cin * 16 * L->CoutPad; }
     }
-    for (Conv* L : wino_list) launch_wino_weights(L->w->dev, L->wino, L->Cin, L->CoutPad, stream);
+    {
+        std::vector<WinoWDesc> d;
+        for (Conv* L : wino_list) d.push_back(WinoWDesc{L->w->dev, L->wino, L->Cin, L->CoutPad});
+        run_wino_batch(wb_fwd, d, false);
+    }
     auto cin_pad = [](const Conv* L) { return (L->Cin + 31) / 32 * 32; };
     if (mfma_mode == 2) {
         // bf16-plane copies for the launches that can take the split kernel: the 64-cout Winograd variant only (conv_wino.hip)
@@ -368,7 +372,11 @@ void Model::refresh_wino(bool with_dgrad) {
             size_t off = 0;
             for (Conv* L : wino_list) if (fwd6(L)) { L->wino6 = wino6_arena + off; off += wino_weights6_bytes(L->Cin, L->CoutPad); }
         }
-        for (Conv* L : wino_list) if (fwd6(L)) launch_wino_weights6(L->w->dev, L->wino6, L->Cin, L->CoutPad, stream);
+        {
+            std::vector<WinoWDesc> d;
+            for (Conv* L : wino_list) if (fwd6(L)) d.push_back(WinoWDesc{L->w->dev, L->wino6, L->Cin, L->CoutPad});
+            run_wino_batch(wb_fwd6, d, true);
+        }
         if (with_dgrad) {
             if (!winot6_arena) {
                 size_t total = 0;
@@ -377,10 +385,12 @@ void Model::refresh_wino(bool with_dgrad) {
                 size_t off = 0;
                 for (Conv* L : wino_list) if (bwd6(L)) { winot6_of[L->w] = winot6_arena + off; off += wino_weights6_bytes(L->Cout, cin_pad(L)); }
             }
+            std::vector<WinoWDesc> d;
             for (Conv* L : wino_list) {
                 auto it = wt_of.find(L->w);
-                if (bwd6(L) && it != wt_of.end()) launch_wino_weights6(it->second, winot6_of[L->w], L->Cout, cin_pad(L), stream);
+                if (bwd6(L) && it != wt_of.end()) d.push_back(WinoWDesc{it->second, winot6_of[L->w], L->Cout, cin_pad(L)});
             }
+            run_wino_batch(wb_bwd6, d, true);
         }
     }
     if (!with_dgrad) return;
@@ -391,10 +401,33 @@ void Model::refresh_wino(bool with_dgrad) {
         size_t off = 0;
         for (Conv* L : wino_list) { winot_of[L->w] = winot_arena + off; off += (size_t)L->Cout * 16 * cin_pad(L); }
     }
+    std::vector<WinoWDesc> d;
     for (Conv* L : wino_list) {
         auto it = wt_of.find(L->w);
-        if (it != wt_of.end()) launch_wino_weights(it->second, winot_of[L->w], L->Cout, cin_pad(L), stream);
+        if (it != wt_of.end()) d.push_back(WinoWDesc{it->second, winot_of[L->w], L->Cout, cin_pad(L)});
     }
+    run_wino_batch(wb_bwd, d, false);
+}
+
+// One launch for a whole descriptor table; the device copy is re-uploaded only when the table changed.
+void Model::run_wino_batch(WinoBatch& b, std::vector<WinoWDesc>& descs, bool split6) {
+    if (descs.empty()) return;
+    bool same = b.dev && b.host.size() == descs.size();
+    for (size_t i = 0; same && i < descs.size(); ++i)
+        same = b.host[i].w == descs[i].w && b.host[i].u == descs[i].u && b.host[i].Cin == descs[i].Cin && b.host[i].CoutPad == descs[i].CoutPad;
+    if (!same) {
+        VR_HIP(hipStreamSynchronize(stream));                       // (a launch may still read the old table)
+        if (b.dev) VR_HIP(hipFree(b.dev));
+        VR_HIP(hipMalloc(reinterpret_cast<void**>(&b.dev), descs.size() * sizeof(WinoWDesc)));
+        VR_HIP(hipMemcpy(b.dev, descs.data(), descs.size() * sizeof(WinoWDesc), hipMemcpyHostToDevice));
+        b.host = descs;
+        b.max_elems = 0;
+        for (const WinoWDesc& e : descs) {
+            const long long cin = split6 ? (e.Cin + 7) / 8 * 8 : e.Cin;
+            b.max_elems = std::max(b.max_elems, cin * e.CoutPad);
+        }
+    }
+    launch_wino_weights_batched(b.dev, (int)descs.size(), b.max_elems, split6, stream);
 }
 
 // =====================================================================================================
