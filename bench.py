@@ -143,8 +143,8 @@ def self_launch(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--mode', choices=['all', 'infer', 'tta', 'train'], default='all')
     ap.add_argument('--seconds', type=float, default=30.0)
     ap.add_argument('--tta', action='store_true', help='same as --mode tta')
