@@ -136,6 +136,9 @@ PLAIN_CASES = [
     (2, 40, 16, 32, 8, 1, 1, 1, 1, 1, 0.0, 0),           # 1x1
     (1, 320, 32, 16, 64, 1, 1, 1, 1, 1, 0.0, 1),         # 1x1, 16-wide, K = 320
     (1, 128, 5, 64, 256, 1, 1, 1, 1, 0, 1.0, 1),
+    (2, 49, 24, 64, 16, 3, 1, 1, 1, 1, 0.0, 0),          # <= 16 couts: conv_thin.hip (16x16x4 MFMA), dec1-like
+    (1, 25, 17, 96, 8, 3, 1, 1, 1, 1, 0.01, 1),          # 8 couts, odd H, bias + epilogue
+    (3, 10, 40, 48, 16, 3, 1, 1, 1, 0, 1.0, 0),          # partial 32-column tile, Cin not a multiple of 4
 ]
 
 
