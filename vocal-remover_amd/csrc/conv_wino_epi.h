@@ -8,10 +8,8 @@
 namespace vr {
 
 // Exchange buffer of one pass: [f 16][register pair 8][lane 64] x 8 bytes = 64 KB, + [MT][2] BatchNorm partial sums.
-// (Exchanging both pixel halves of a cout half per barrier -- 2 x 64 KB, possible in the 64-cout kernels -- was measured: no
-// gain for the fp32 kernel, and the split-bf16 kernel's main loop came out 6 % slower from the changed register allocation.)
-__host__ __device__ constexpr int wino_epilogue_passes(int) { return 1; }
-__host__ __device__ constexpr int wino_epilogue_floats(int MT) { return wino_epilogue_passes(MT) * 16 * 8 * 64 * 2 + 2 * MT; }
+// (Exchanging both pixel halves of a cout half per barrier -- 2 x 64 KB, possible in the 64-cout kernels -- was measured: no gain.)
+__host__ __device__ constexpr int wino_epilogue_floats(int MT) { return 16 * 8 * 64 * 2 + 2 * MT; }
 
 // The lanes of all 8 waves own the SAME (cout, tile) pairs -- accumulator register r of lane (khalf, l31) is cout
 // (r & 3) + 8 (r >> 2) + 4 khalf, tile l31 -- for different frequencies, so the exchange is wave-to-wave at a fixed lane: every
@@ -22,33 +20,28 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& a, f32x16 (&acc)[2
                                               int khalf, int l31, int n, int h0, int w0, int co0, int pt) {
     constexpr int WM = MT / 32;
     if (a.dbg == 4) return;                                            // (ablation: no epilogue, no stores)
-    constexpr int NP = wino_epilogue_passes(MT), PASS = 16 * 8 * 64;   // float2 elements of one pass
-    vr_f32x2* Mx = reinterpret_cast<vr_f32x2*>(smem);                  // [NP][16][8][64]
-    float* stat = smem + NP * PASS * 2;                                // [MT][2] BatchNorm partial sums (training)
+    vr_f32x2* Mx = reinterpret_cast<vr_f32x2*>(smem);                  // [16][8][64]
+    float* stat = smem + 16 * 8 * 64 * 2;                              // [MT][2] BatchNorm partial sums (training)
     const int lane = khalf * 32 + l31;
     if (a.part && tid < 2 * MT) stat[tid] = 0.f;                       // (ordered by the first pass's barriers)
 #pragma unroll
     for (int mi = 0; mi < WM; ++mi) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-            if (ni % NP == 0) {
-                if (mi + ni > 0) lds_barrier();                        // previous exchange has been read
+            if (mi + ni > 0) lds_barrier();                            // previous pass has been read
 #pragma unroll
-                for (int np = 0; np < NP; ++np)
+            for (int fi = 0; fi < 2; ++fi)
 #pragma unroll
-                    for (int fi = 0; fi < 2; ++fi)
-#pragma unroll
-                        for (int rp = 0; rp < 8; ++rp) {
-                            vr_f32x2 v;
-                            v[0] = acc[fi][mi][ni + np][2 * rp];
-                            v[1] = acc[fi][mi][ni + np][2 * rp + 1];
-                            Mx[np * PASS + ((2 * wave + fi) * 8 + rp) * 64 + lane] = v;
-                        }
-                lds_barrier();
-            }
+                for (int rp = 0; rp < 8; ++rp) {
+                    vr_f32x2 v;
+                    v[0] = acc[fi][mi][ni][2 * rp];
+                    v[1] = acc[fi][mi][ni][2 * rp + 1];
+                    Mx[((2 * wave + fi) * 8 + rp) * 64 + lane] = v;
+                }
+            lds_barrier();
             vr_f32x2 mm[16];
 #pragma unroll
-            for (int f = 0; f < 16; ++f) mm[f] = Mx[(ni % NP) * PASS + (f * 8 + wave) * 64 + lane];
+            for (int f = 0; f < 16; ++f) mm[f] = Mx[(f * 8 + wave) * 64 + lane];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int r = 2 * wave + j;
