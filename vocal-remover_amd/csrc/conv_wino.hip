@@ -16,10 +16,13 @@
 //   * wave w transforms ITS OWN channel (lane = tile; 16 LDS reads, 32 adds, 16 LDS writes) -- no
 //     cross-wave dependency between the DMA and the transform, so one barrier per chunk suffices;
 //   * wave w multiplies frequencies 2w and 2w+1 (accumulators 2 x MT/32 x 2 tiles of 32x32);
-//   * epilogue: the 16 frequencies of a (cout, tile) pair live in 8 different waves, so they meet in
-//     LDS (32 couts x 32 tiles per pass), A^T M A, bias / folded BatchNorm / activation, 8-byte stores.
+//   * epilogue (conv_wino_epi.h): the 16 frequencies of a (cout, tile) pair live in 8 different waves, so
+//     they meet in LDS (32 couts x 32 tiles per pass), A^T M A, bias / folded BatchNorm / activation,
+//     8-byte stores, BatchNorm partial sums in training.
 // fp32 throughout; the transforms only add and halve, the measured deviation from the direct kernel
-// is ~1e-6 relative (tests/test_gpu_parity.py::test_conv_winograd_vs_direct).
+// is ~1e-6 relative (tests/test_gpu_parity.py::test_conv_winograd_vs_torch).
+// Measured with the SQ counters (profiles/r02_*_sq_pmc.md): the matrix pipe is busy 0.50 (64 couts) / 0.41 (32 couts) of
+// the kernel's time; transform, DMA issue, the per-chunk barriers and the epilogue are serial with the MFMA phase.
 #include <cstdlib>
 
 #include "conv_wino_epi.h"
