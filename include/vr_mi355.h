@@ -120,6 +120,10 @@ int vr_train_step(vr_handle h, const float* X, const float* y, int on_device, in
  * call vr_set_option(h, "params_dirty", 1) after writing it so that eval-mode folded tables are rebuilt.            */
 int vr_forward_train(vr_handle h, const float* X, int on_device, int B, int T, float* mask_out, int mask_on_device);
 int vr_backward(vr_handle h, const float* dmask, int on_device);
+/* Identity of the graph the handle currently holds: *generation counts the vr_forward_train calls so far, *valid (may be
+ * NULL) says whether that graph is still alive.  A caller that keeps several forward results around (autograd) records the
+ * generation after vr_forward_train and refuses to call vr_backward for any other one -- the handle keeps ONE graph. */
+int vr_graph_generation(vr_handle h, int64_t* generation, int* valid);
 int vr_param_arena(vr_handle h, float** device_ptr, int64_t* numel);
 
 /* Training input pipeline on the device: replaces the numeric part of

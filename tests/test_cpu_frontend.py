@@ -18,7 +18,8 @@ def test_wav_codec_round_trip_and_encodings(vr, tmp_path):
     vr.audio.write(p, x, 44100)
     y, sr = vr.audio.read_wav(p)
     assert sr == 44100 and y.shape == (2, 1000)
-    assert np.abs(y.T - np.clip(x, -1, 32767 / 32768)).max() <= 0.5 / 32768 + 1e-7
+    # written as rint(x * 0x7FFF) (libsndfile's default float -> PCM_16 scale), read back as q / 0x8000
+    assert np.array_equal(y.T, np.clip(np.rint(x * 32767.0), -32768, 32767).astype(np.float32) / 32768)
     # scipy writes the other encodings; the reader must agree with scipy's reader
     import scipy.io.wavfile as wf
     for dt, tol in ((np.int32, 1e-9), (np.float32, 0.0), (np.uint8, 1e-9), (np.float64, 1e-7)):

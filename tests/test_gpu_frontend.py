@@ -161,7 +161,8 @@ def test_inference_main_wav_in_wav_out(vr, tmp_path):
     y_wave, v_wave = vr.inference.Separator(m, torch.device(DEV), batchsize=4, cropsize=256).separate_wave(X)
     assert yi.shape == y_wave.shape
     q = 0.5 / 32768 + 1e-6                                                        # 16-bit PCM quantisation
-    assert np.abs(yi - np.clip(y_wave, -1, 32767 / 32768)).max() <= q and np.abs(vi - np.clip(v_wave, -1, 32767 / 32768)).max() <= q
+    k = 32767 / 32768                                                             # written x * 0x7FFF, read q / 0x8000
+    assert np.abs(yi - np.clip(y_wave, -1, 1) * k).max() <= q and np.abs(vi - np.clip(v_wave, -1, 1) * k).max() <= q
     assert np.abs(y_wave + v_wave - X[:, :y_wave.shape[1]]).max() < 1e-4
 
 

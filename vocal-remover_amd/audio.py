@@ -64,12 +64,13 @@ def read_wav(path):
 
 
 def write(path, data, sr):
-    """soundfile.write(path, data [samples, channels] (or [samples]), sr): 16-bit PCM, clipped like libsndfile does."""
+    """soundfile.write(path, data [samples, channels] (or [samples]), sr): 16-bit PCM.  libsndfile's default float -> PCM_16
+    path (normalisation on, clipping off: f2s_array) scales by 0x7FFF and rounds to nearest; the clip is only a guard."""
     data = np.asarray(data, dtype=np.float32)
     if data.ndim == 1:
         data = data[:, None]
     n, ch = data.shape
-    pcm = np.clip(np.rint(data * 32768.0), -32768, 32767).astype('<i2')       # libsndfile: lrintf(x * 0x8000), clipped
+    pcm = np.clip(np.rint(data * 32767.0), -32768, 32767).astype('<i2')
     body = pcm.tobytes()
     with open(path, 'wb') as f:
         f.write(b'RIFF' + struct.pack('<I', 36 + len(body)) + b'WAVE')

@@ -182,6 +182,15 @@ int vr_backward(vr_handle h, const float* dmask, int on_device) {
     return guard([&] { h->m.backward_api(dmask, on_device != 0); });
 }
 
+int vr_graph_generation(vr_handle h, int64_t* generation, int* valid) {
+    NEED(h);
+    return guard([&] {
+        VR_CHECK(generation, VR_ERR_BAD_ARGUMENT, "null argument");
+        *generation = h->m.graph_gen;
+        if (valid) *valid = h->m.graph_valid ? 1 : 0;
+    });
+}
+
 int vr_param_arena(vr_handle h, float** device_ptr, int64_t* numel) {
     NEED(h);
     return guard([&] {

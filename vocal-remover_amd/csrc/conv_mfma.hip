@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 #include "conv_stage.h"
+#include "kernels.h"
 
 namespace vr {
 
@@ -340,6 +341,8 @@ void conv_fill_tiling(ConvArgs& a, const ConvShape& s) {
     int wmt, wth;
     int wino_mt, thin_th;
     if (thin16_pick(a, s, &thin_th)) { thin16_fill_tiling(a, thin_th); return; }
+    X3Tile x3t;
+    if (x3_pick(a, s, &x3t)) { x3_fill_tiling(a, x3t); return; }
     if (wino_pick(a, s, &wino_mt)) { wino_fill_tiling(a, wino_mt); return; }
     DmaTile dt;
     if (dma_pick(a, s, &dt)) { dma_fill_tiling(a, dt); return; }
@@ -398,6 +401,12 @@ double launch_conv(const ConvArgs& a_in, const ConvShape& s, hipStream_t st) {
         if (a.nsrc >= 1 && a.nsrc <= 3 && thin16_pick(a, s, &thin_th)) {
             thin16_fill_tiling(a, thin_th);
             thin16_launch_conv(a, s, thin_th, st);
+            return 2.0 * a.N * (double)a.Hout * a.Wout * (double)a.Cout * a.Cin * s.KS * s.KS;
+        }
+        X3Tile x3t;
+        if (a.nsrc >= 1 && a.nsrc <= 3 && x3_pick(a, s, &x3t)) {
+            x3_fill_tiling(a, x3t);
+            x3_launch_conv(a, x3t, st);
             return 2.0 * a.N * (double)a.Hout * a.Wout * (double)a.Cout * a.Cin * s.KS * s.KS;
         }
         if (a.nsrc >= 1 && a.nsrc <= 3 && wino_pick(a, s, &wino_mt)) {

@@ -1,0 +1,461 @@
+// Direct 3x3 stride-1 convolution with fp32 products on the bf16 matrix pipe ("mfma_mode" 2; lib/layers.py:12-20).
+//
+// gfx950 multiplies fp32 operands on v_mfma_f32_32x32x2_f32 at the fp32 VECTOR rate (1/16 of the bf16 matrix rate), so an
+// fp32-exact product assembled from six bf16 products (conv_stage.h: x = x1 + x2 + x3, three exact bf16 planes per operand)
+// costs 3 x 32 cycles per 8 input channels where the fp32 instruction needs 4 x 64: a 2.67x higher multiply roof for the
+// DIRECT convolution -- above what Winograd F(2x2,3x3) buys on the fp32 pipe (2.25x), with no input / output transforms,
+// 9/16 of the weight bytes and no 16-frequency exchange in the epilogue.
+//
+// Workgroup = 256 threads / 4 waves, output tile TH x 32 pixels x MT couts, input channels in chunks of 8:
+//   * each thread owns up to NPASS pixels ("slots") of the (TH+2) x 34 halo tile: it loads the 8 channels of its pixel with
+//     plain buffer_load_dword (one coalesced row segment per wave instruction; conv zero padding = out-of-range offsets),
+//     issued BEFORE the MFMA phase of the previous chunk so the latency is covered, splits the four channel pairs into the three
+//     bf16 planes (11 VALU per pair) and stores  P[plane][row][col][8 ch]  = one 16-byte MFMA operand per pixel and plane;
+//   * the weights arrive pre-split (x3_weights_kernel: [chunk][tap][plane][cout][8 ch]) by LDS-DMA, double-buffered;
+//   * multiply phase = ds_read_b128 + MFMA only.  With  A = [a1|a1], [a2|a2], [a3|a1]  and  B = [b1|b2], [b1|b3]  (lanes 0-31
+//     hold k = 0..7, lanes 32-63 k = 8..15: both halves carry the SAME 8 channels of two planes)
+//         [a1|a1][b1|b2] + [a2|a2][b1|b2] + [a3|a1][b1|b3] = a1b1 + a1b2 + a2b1 + a2b2 + a3b1 + a1b3
+//     per tap: 3 WM + 2 WN operand reads feed 3 WM WN instructions; operands of tap t+1 are read before the MFMAs of tap t;
+//   * two barriers per chunk (P is single-buffered: 16-29 KB; the two weight buffers take 28-55 KB) -- two or three workgroups
+//     per CU overlap one's split pass with the others' multiply phases.
+// The epilogue is conv_dma.hip's (same 32x32 accumulator layout): bias, folded BatchNorm + activation (eval), up to three
+// destination segments, BatchNorm partial sums (training).
+#include <cstdlib>
+
+#include "conv_stage.h"
+#include "kernels.h"
+#include "lds_dma.h"
+
+#ifndef X3_VARIANT
+#define X3_VARIANT 0
+#endif
+
+namespace vr {
+
+__device__ float x3_buffer_load(i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+
+template <int MT, int TH>
+struct X3Cfg {
+    static constexpr int TW = 32, CK = 8, KK = 9;
+    static constexpr int TH_in = TH + 2, PW = TW + 2;           // halo tile, pixels
+    static constexpr int NSLOT = TH_in * PW;
+    static constexpr int NPASS = (NSLOT + 255) / 256;
+    static constexpr int WM = MT / 32, WN = TH / 4;
+    static constexpr int PLANE = NSLOT * 16;                     // bytes of one bf16 plane (8 channels per pixel)
+    static constexpr int P_BYTES = 3 * PLANE;
+    static constexpr int NWP = KK * 3 * MT;                      // 16-byte weight operands per chunk
+    static constexpr int W_BYTES = NWP * 16;
+    static constexpr int NWPASS = (NWP + 255) / 256;
+    static constexpr int LDS_BYTES = P_BYTES + 2 * W_BYTES;
+    static constexpr int OCC = 3 * LDS_BYTES <= 160 * 1024 ? 3 : 2;   // workgroups per CU the register budget must allow
+    static_assert(TH % 4 == 0 && MT % 32 == 0 && LDS_BYTES <= 80 * 1024, "tile");
+};
+
+template <int MT, int TH>
+__global__ __launch_bounds__(256, (X3Cfg<MT, TH>::OCC)) void conv_x3_kernel(const ConvArgs a) {
+    using Cfg = X3Cfg<MT, TH>;
+    constexpr int TW = Cfg::TW, KK = Cfg::KK, PW = Cfg::PW, NSLOT = Cfg::NSLOT, NPASS = Cfg::NPASS, WM = Cfg::WM, WN = Cfg::WN,
+                  PLANE = Cfg::PLANE, NWP = Cfg::NWP, NWPASS = Cfg::NWPASS;
+    extern __shared__ __attribute__((aligned(16))) char smem_x3[];
+    char* const Pb = smem_x3;
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int rr = id >> 3;
+    const int ct = rr % a.nct;
+    const int pt = (rr / a.nct) * 8 + xcd;
+    if (pt >= a.npt) return;
+    const int tiles_per_img = a.tiles_h * a.tiles_w;
+    const int n = pt / tiles_per_img;
+    const int trem = pt - n * tiles_per_img;
+    const int h0 = (trem / a.tiles_w) * TH;
+    const int w0 = (trem % a.tiles_w) * TW;
+    const int co0 = ct * MT;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nchunk = (a.Cin + 7) >> 3;
+    const unsigned lds0 = (unsigned)(size_t)smem_x3;
+
+    // ---- this thread's pixels of the halo tile: byte offset in the source = hrow * (4 * sH) + wcol4 (2^31: padding) ----
+    unsigned hrow[NPASS], wcol4[NPASS];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int s = p * 256 + tid;
+        const int r = s / PW, c = s - r * PW;
+        const int hi = h0 - 1 + r, wi = w0 - 1 + c;
+        const bool ok = s < NSLOT && hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win;
+        hrow[p] = ok ? (unsigned)hi : 0u;
+        wcol4[p] = ok ? (unsigned)(wi * 4) : 0x80000000u;
+    }
+    // ---- weight operands: LDS order [tap][plane][m], source x3w[chunk][(tap * 3 + plane) * CoutPad + co0 + m] ----
+    unsigned woff[NWPASS];
+#pragma unroll
+    for (int i = 0; i < NWPASS; ++i) {
+        const int q = (wave + 4 * i) * 64 + lane;
+        const int m = q % MT, tp = q / MT;
+        woff[i] = (unsigned)((tp * a.CoutPad + m) * 16);
+    }
+    const long long wchunk_bytes = (long long)KK * 3 * a.CoutPad * 16;
+
+    auto issue_w = [&](int k) {
+        const char* wb = static_cast<const char*>(a.x3w) + k * wchunk_bytes + (long long)co0 * 16;
+        const i32x4 wr = make_rsrc(reinterpret_cast<const float*>(wb), (unsigned)(wchunk_bytes - (long long)co0 * 16));
+        const unsigned ws_b = lds0 + (unsigned)(Cfg::P_BYTES + (k & 1) * Cfg::W_BYTES);
+#pragma unroll
+        for (int i = 0; i < NWPASS; ++i) {
+            const int pp = wave + 4 * i;
+            if ((pp + 1) * 64 <= NWP) dma16(ws_b + pp * 1024, woff[i], wr);
+            else if (pp * 64 + lane < NWP) dma16(ws_b + pp * 1024, woff[i], wr);
+        }
+    };
+    // The channels are visited strictly in order (chunk by chunk), so the source of the virtual concat is a running scalar
+    // state: pointer to the current channel's plane, its channel / row strides, the first channel of the next source.
+    const float* xp = a.src[0].p + (long long)n * a.src[0].sN;
+    long long xsC = a.src[0].sC;
+    unsigned xsH4 = (unsigned)a.src[0].sH * 4u;
+    int xend = a.c1, xsi = 0;
+    int xvo[NPASS];                                            // byte offset of this thread's pixels in a channel plane of the current source
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) xvo[p] = (int)(hrow[p] * xsH4 + wcol4[p]);
+    float xr[NPASS][8];
+    auto next_source = [&]() {
+        ++xsi;
+        if (xsi == 1) { xp = a.src[1].p + (long long)n * a.src[1].sN; xsC = a.src[1].sC; xsH4 = (unsigned)a.src[1].sH * 4u; xend = a.c2; }
+        else { xp = a.src[2].p + (long long)n * a.src[2].sN; xsC = a.src[2].sC; xsH4 = (unsigned)a.src[2].sH * 4u; xend = 1 << 30; }
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) xvo[p] = (int)(hrow[p] * xsH4 + wcol4[p]);
+    };
+    // NB straight-line code on purpose (no loop, the loads unconditional): hipcc's wait-count pass flushes vmcnt in front of
+    // any inner loop and protects conditionally loaded registers with a vmcnt(0) at the top of the next chunk -- right behind
+    // the weight DMA just issued, i.e. one exposed DMA latency per chunk (measured on the first version: 680 vs 406 us).
+    auto load_x = [&](int k) {
+#pragma unroll
+        for (int cl = 0; cl < 8; ++cl) {
+            const int ci = k * 8 + cl;                            // wave-uniform
+            const bool live = ci < a.Cin && a.dbg != 1;
+            if (live && ci >= xend) next_source();                // (a source may be a single channel: two steps at most)
+            if (live && ci >= xend) next_source();
+            const i32x4 xs = make_rsrc(xp, live ? 0x7FFFFFF0u : 0u);      // channels beyond Cin: an empty descriptor reads zeros
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) xr[p][cl] = x3_buffer_load(xs, xvo[p], 0, 0);
+            if (live) xp += xsC;
+        }
+    };
+    auto convert = [&]() {
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const int s = p * 256 + tid;
+            if ((p + 1) * 256 <= NSLOT || s < NSLOT) {
+                vr_i32x4 ph, pm, pl;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int h, m, l;
+                    split3_pair(xr[p][2 * j], xr[p][2 * j + 1], h, m, l);
+                    ph[j] = h; pm[j] = m; pl[j] = l;
+                }
+                char* q = Pb + s * 16;
+                *reinterpret_cast<vr_i32x4*>(q) = ph;
+                *reinterpret_cast<vr_i32x4*>(q + PLANE) = pm;
+                *reinterpret_cast<vr_i32x4*>(q + 2 * PLANE) = pl;
+            }
+        }
+    };
+
+    const int khalf = lane >> 5, l31 = lane & 31;
+    // B operands [b1|b2] and [b1|b3]: lanes 0-31 read plane 0, lanes 32-63 plane 1 resp. 2; pixel (row wave*WN + ni + ty, col l31 + tx)
+    const int bb0 = (khalf * NSLOT + wave * WN * PW + l31) * 16;
+    const int bb1 = (2 * khalf * NSLOT + wave * WN * PW + l31) * 16;
+    // A operands [a1|a1], [a2|a2], [a3|a1]
+    const int ab0 = l31 * 16, ab1 = (MT + l31) * 16, ab2 = ((khalf ? 0 : 2) * MT + l31) * 16;
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    // NB the waits in front of the chunk barriers are the BUILTIN, not inline asm: hipcc's wait-count pass must see that the
+    // pixel loads have retired, or it protects their registers (written again by the next load_x) with a vmcnt(0) of its own --
+    // placed right behind the weight DMA of the next chunk, i.e. one exposed DMA latency per chunk (measured: 680 -> 406 us).
+    issue_w(0);
+    load_x(0);
+    convert();
+    __builtin_amdgcn_s_waitcnt(0x0070);                      // vmcnt(0) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    for (int k = 0; k < nchunk; ++k) {
+        const bool more = k + 1 < nchunk;
+        if (more) { issue_w(k + 1); load_x(k + 1); }
+        if (a.dbg != 2) {
+            const char* Wb = smem_x3 + Cfg::P_BYTES + (k & 1) * Cfg::W_BYTES;
+            vr_bf16x8 A[2][3][WM], B[2][2][WN];
+            // operand reads of tap t, in the order the MFMA groups consume them: part 0 = [a3|a1] + [b1|b3], part 1 = [a2|a2] + [b1|b2],
+            // part 2 = [a1|a1]
+            auto read_part = [&](int t, int buf, int part) {
+                const int ty = t / 3, tx = t % 3;
+#pragma unroll
+                for (int mi = 0; mi < WM; ++mi) {
+                    const char* q = Wb + (t * 3 * MT + mi * 32) * 16;
+                    if (part == 0) A[buf][2][mi] = *reinterpret_cast<const vr_bf16x8*>(q + ab2);
+                    if (part == 1) A[buf][1][mi] = *reinterpret_cast<const vr_bf16x8*>(q + ab1);
+                    if (part == 2) A[buf][0][mi] = *reinterpret_cast<const vr_bf16x8*>(q + ab0);
+                }
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni) {
+                    const int o = ((ni + ty) * PW + tx) * 16;
+                    if (part == 0) B[buf][1][ni] = *reinterpret_cast<const vr_bf16x8*>(Pb + bb1 + o);
+                    if (part == 1) B[buf][0][ni] = *reinterpret_cast<const vr_bf16x8*>(Pb + bb0 + o);
+                }
+            };
+            auto mfma_group = [&](int buf, int ja, int jb) {
+#pragma unroll
+                for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni) acc[mi][ni] = mfma_bf16x16(A[buf][ja][mi], B[buf][jb][ni], acc[mi][ni]);
+            };
+            read_part(0, 0, 0); read_part(0, 0, 1); read_part(0, 0, 2);
+#pragma unroll
+            for (int t = 0; t < KK; ++t) {
+                const int cur = t & 1;
+#if X3_VARIANT == 1
+                // the reads of tap t+1 go out in three bursts between the three MFMA groups of tap t
+                if (t + 1 < KK) read_part(t + 1, cur ^ 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_group(cur, 2, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < KK) read_part(t + 1, cur ^ 1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_group(cur, 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < KK) read_part(t + 1, cur ^ 1, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_group(cur, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#else
+                if (t + 1 < KK) { read_part(t + 1, cur ^ 1, 0); read_part(t + 1, cur ^ 1, 1); read_part(t + 1, cur ^ 1, 2); }
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_group(cur, 2, 1);
+                mfma_group(cur, 1, 0);
+                mfma_group(cur, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+        }
+        if (more) {
+            lds_barrier();                                   // every wave has read P(k)
+            if (a.dbg != 3) convert();                        // (the compiler waits for the pixel loads; the weight DMA was issued before them)
+            __builtin_amdgcn_s_waitcnt(0x0070);              // vmcnt(0) lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();                    // P(k+1) complete, W(k+1) landed
+            asm volatile("" ::: "memory");
+        }
+    }
+
+    // ---------------- epilogue (as conv_dma.hip): bias, (eval) BatchNorm + activation, up to three destination segments -------
+    if (a.dbg == 4) return;
+    if (a.d1 >= a.CoutPad) {
+        long long offn[WN];
+        bool okn[WN];
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) {
+            const int ho = h0 + wave * WN + ni, wo = w0 + l31;
+            okn[ni] = ho < a.Hout && wo < a.Wout && a.dst[0].p != nullptr;
+            offn[ni] = (long long)ho * a.dst[0].sH + ((long long)wo << a.dst[0].wshift);
+        }
+        float* dbase = a.dst[0].p + (long long)n * a.dst[0].sN;
+        const int dacc = a.dst[0].accumulate;
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                const int cc = co < a.Cout ? co : a.Cout - 1;
+                const float b = a.bias ? a.bias[cc] : 0.f;
+                float esc = 1.f, esh = 0.f, eslope = 1.f;
+                if (a.epi) { esc = a.epi[2 * cc]; esh = a.epi[2 * cc + 1]; eslope = a.epi_slope; }
+                float* qrow = dbase + (long long)co * a.dst[0].sC;
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni) {
+                    const float v = acc[mi][ni][r] + b;
+                    acc[mi][ni][r] = v;
+                    if (co < a.Cout && okn[ni]) {
+                        float* q = qrow + offn[ni];
+                        const float y = act_apply(fmaf(v, esc, esh), eslope);
+                        *q = dacc ? *q + y : y;
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                const int cc = co < a.Cout ? co : a.Cout - 1;
+                const float b = a.bias ? a.bias[cc] : 0.f;
+                float esc = 1.f, esh = 0.f, eslope = 1.f;
+                if (a.epi) { esc = a.epi[2 * cc]; esh = a.epi[2 * cc + 1]; eslope = a.epi_slope; }
+                const int seg = (co >= a.d1) + (co >= a.d2);
+                const int cod = co - (seg == 0 ? 0 : (seg == 1 ? a.d1 : a.d2));
+                float* dp = seg == 0 ? a.dst[0].p : (seg == 1 ? a.dst[1].p : a.dst[2].p);
+                const long long dN = seg == 0 ? a.dst[0].sN : (seg == 1 ? a.dst[1].sN : a.dst[2].sN);
+                const long long dC = seg == 0 ? a.dst[0].sC : (seg == 1 ? a.dst[1].sC : a.dst[2].sC);
+                const long long dH = seg == 0 ? a.dst[0].sH : (seg == 1 ? a.dst[1].sH : a.dst[2].sH);
+                const int dacc = seg == 0 ? a.dst[0].accumulate : (seg == 1 ? a.dst[1].accumulate : a.dst[2].accumulate);
+                const int dws = seg == 0 ? a.dst[0].wshift : (seg == 1 ? a.dst[1].wshift : a.dst[2].wshift);
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni) {
+                    const int ho = h0 + wave * WN + ni, wo = w0 + l31;
+                    const float v = acc[mi][ni][r] + b;
+                    acc[mi][ni][r] = v;
+                    if (co < a.Cout && ho < a.Hout && wo < a.Wout && dp) {
+                        float* q = dp + (long long)n * dN + (long long)cod * dC + (long long)ho * dH + ((long long)wo << dws);
+                        const float y = act_apply(fmaf(v, esc, esh), eslope);
+                        *q = dacc ? *q + y : y;
+                    }
+                }
+            }
+        }
+    }
+    // ---------------- BatchNorm partial statistics (training) -------------------------------------------------
+    if (a.part) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem_x3);                     // [4 waves][MT][2]
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni) {
+                    const int ho = h0 + wave * WN + ni, wo = w0 + l31;
+                    if (ho < a.Hout && wo < a.Wout) {
+                        const float v = acc[mi][ni][r];
+                        s1 += v;
+                        s2 = fmaf(v, v, s2);
+                    }
+                }
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) {
+                    s1 += __shfl_xor(s1, off, 64);
+                    s2 += __shfl_xor(s2, off, 64);
+                }
+                if (l31 == 0) {
+                    const int m = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    red[(wave * MT + m) * 2 + 0] = s1;
+                    red[(wave * MT + m) * 2 + 1] = s2;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < MT) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                s1 += red[(w * MT + tid) * 2 + 0];
+                s2 += red[(w * MT + tid) * 2 + 1];
+            }
+            const int co = co0 + tid;
+            if (co < a.Cout) {
+                a.part[((long long)pt * a.Cout + co) * 2 + 0] = s1;
+                a.part[((long long)pt * a.Cout + co) * 2 + 1] = s2;
+            }
+        }
+    }
+}
+
+// ---- weights as three bf16 planes: w [Cin][KK][CoutPad] fp32 -> x3w [ceil(Cin/8)][KK][3][CoutPad][8 channels] ------------
+__device__ __forceinline__ void x3_weights_elem(const float* __restrict__ w, unsigned short* __restrict__ o, int Cin, int KK, int CoutPad,
+                                                long long gid) {
+    const int cin8 = (Cin + 7) / 8 * 8;
+    if (gid >= (long long)cin8 * KK * CoutPad) return;
+    const int co = (int)(gid % CoutPad);
+    const int t = (int)((gid / CoutPad) % KK);
+    const int ci = (int)(gid / ((long long)CoutPad * KK));
+    const float v = ci < Cin ? w[((long long)ci * KK + t) * CoutPad + co] : 0.f;
+    int p1, p2, p3;
+    split3_pair(v, 0.f, p1, p2, p3);
+    unsigned short* q = o + ((((long long)(ci >> 3) * KK + t) * 3) * CoutPad + co) * 8 + (ci & 7);
+    q[0] = (unsigned short)(p1 & 0xffff);
+    q[(long long)CoutPad * 8] = (unsigned short)(p2 & 0xffff);
+    q[2LL * CoutPad * 8] = (unsigned short)(p3 & 0xffff);
+}
+__global__ void x3_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ o, int Cin, int KK, int CoutPad) {
+    x3_weights_elem(w, o, Cin, KK, CoutPad, (long long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+__global__ void x3_weights_batched_kernel(const X3WDesc* __restrict__ d) {
+    const X3WDesc e = d[blockIdx.y];
+    x3_weights_elem(e.w, static_cast<unsigned short*>(e.o), e.Cin, e.KK, e.CoutPad, (long long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+size_t x3_weights_bytes(int Cin, int KK, int CoutPad) { return (size_t)((Cin + 7) / 8) * KK * 3 * CoutPad * 16; }
+
+void launch_x3_weights(const float* w, void* o, int Cin, int KK, int CoutPad, hipStream_t st) {
+    const long long n = (long long)((Cin + 7) / 8 * 8) * KK * CoutPad;
+    hipLaunchKernelGGL(x3_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, static_cast<unsigned short*>(o), Cin, KK,
+                       CoutPad);
+    VR_HIP(hipGetLastError());
+}
+void launch_x3_weights_batched(const X3WDesc* d_descs, int n, long long max_elems, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(x3_weights_batched_kernel, dim3((unsigned)((max_elems + 255) / 256), (unsigned)n), dim3(256), 0, st, d_descs);
+    VR_HIP(hipGetLastError());
+}
+
+template <int MT, int TH>
+static void x3_launch(const ConvArgs& a, hipStream_t st) {
+    using Cfg = X3Cfg<MT, TH>;
+    auto kern = conv_x3_kernel<MT, TH>;
+    static std::atomic<unsigned long long> attr_done{0};
+    ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
+    const int groups = (a.npt + 7) / 8;
+    hipLaunchKernelGGL(kern, dim3(groups * 8 * a.nct), dim3(256), Cfg::LDS_BYTES, st, a);
+    VR_HIP(hipGetLastError());
+}
+
+// True when the launch can take this kernel (3x3 stride-1, plain inputs, split weights available); fills the tile choice.
+bool x3_pick(const ConvArgs& a, const ConvShape& s, X3Tile* t) {
+    static const int enabled = getenv("VR_CONV_X3") ? atoi(getenv("VR_CONV_X3")) : 1;
+    if (!enabled || !a.x3w || a.tapmask) return false;
+    if (!(s.KS == 3 && s.stride == 1 && s.dil_h == 1 && s.dil_w == 1)) return false;
+    if (a.pad_h != 1 || a.pad_w != 1 || a.Wout < 32) return false;
+    for (int i = 0; i < a.nsrc; ++i) {
+        const ConvSrc& c = a.src[i];
+        if (c.aff0 || c.aff1 || c.post || c.up || c.zins || c.slope != 1.f || c.W != a.Win) return false;
+        if ((long long)c.H * (c.sH > 0 ? c.sH : 1) * 4 >= 0x7FFFFFF0LL) return false;
+    }
+    int MT = (a.CoutPad % 64 == 0) ? 64 : 32;
+    int TH = 8;
+    static const int force_mt = getenv("VR_X3_MT") ? atoi(getenv("VR_X3_MT")) : 0;
+    static const int force_th = getenv("VR_X3_TH") ? atoi(getenv("VR_X3_TH")) : 0;
+    const long long tiles8 = (long long)a.N * ((a.Hout + 7) / 8) * ((a.Wout + 31) / 32);
+    if (MT == 64 && tiles8 * (a.CoutPad / 64) < 512) MT = 32;            // fewer than two workgroups per CU: halve the cout tile
+    if (MT == 32) {
+        const long long tiles16 = (long long)a.N * ((a.Hout + 15) / 16) * ((a.Wout + 31) / 32);
+        if (tiles16 * (a.CoutPad / 32) >= 1024) TH = 16;
+    }
+    if (force_mt == 32 || force_mt == 64) MT = (a.CoutPad % force_mt == 0) ? force_mt : MT;
+    if (force_th == 8 || force_th == 16) TH = force_th;
+    if (MT == 64) TH = 8;
+    t->MT = MT; t->TH = TH;
+    return true;
+}
+
+void x3_fill_tiling(ConvArgs& a, const X3Tile& t) {
+    a.tiles_w = (a.Wout + 31) / 32;
+    a.tiles_h = (a.Hout + t.TH - 1) / t.TH;
+    a.npt = a.N * a.tiles_h * a.tiles_w;
+    a.nct = a.CoutPad / t.MT;
+}
+
+void x3_launch_conv(const ConvArgs& a, const X3Tile& t, hipStream_t st) {
+    if (t.MT == 64) x3_launch<64, 8>(a, st);
+    else if (t.TH == 16) x3_launch<32, 16>(a, st);
+    else x3_launch<32, 8>(a, st);
+}
+
+}  // namespace vr

@@ -60,6 +60,15 @@ struct WinoWDesc { const float* w; void* u; int Cin, CoutPad; };                
 void launch_wino_weights_batched(const WinoWDesc* d_descs, int n, long long max_elems, bool split6, hipStream_t st);
 size_t wino_weights6_bytes(int Cin, int CoutPad);                                           // U as three bf16 planes (mfma_mode 2)
 void launch_wino_weights6(const float* w, void* u6, int Cin, int CoutPad, hipStream_t st);
+// conv_x3.hip: direct 3x3 stride-1 conv, fp32 products from six bf16 products (mfma_mode 2)
+struct X3Tile { int MT, TH; };
+struct X3WDesc { const float* w; void* o; int Cin, KK, CoutPad; };                            // one layer of a batched weight split
+bool x3_pick(const ConvArgs& a, const ConvShape& s, X3Tile* t);
+void x3_fill_tiling(ConvArgs& a, const X3Tile& t);
+void x3_launch_conv(const ConvArgs& a, const X3Tile& t, hipStream_t st);
+size_t x3_weights_bytes(int Cin, int KK, int CoutPad);
+void launch_x3_weights(const float* w, void* o, int Cin, int KK, int CoutPad, hipStream_t st);
+void launch_x3_weights_batched(const X3WDesc* d_descs, int n, long long max_elems, hipStream_t st);
 void launch_upsample2x(const Tensor& x, float* out, hipStream_t st);   // dense [N][C][2H][2W], activated
 
 // ---- lstm.hip -----------------------------------------------------------------------------------

@@ -63,6 +63,7 @@ struct Conv {
     float slope = 0.f;              // activation after the BatchNorm
     float* wino = nullptr;          // eval: Winograd-transformed weights [Cin][16][CoutPad] (3x3 stride-1 layers)
     void* wino6 = nullptr;          // mfma_mode 2: the same as three bf16 planes (conv_wino.hip: wino_weights6_kernel)
+    void* x3w = nullptr;            // mfma_mode 2: the direct weights as three bf16 planes (conv_x3.hip: x3_weights_kernel)
 };
 
 struct LSTMMod {
@@ -190,6 +191,12 @@ private:
     char* wino6_arena = nullptr;                         // mfma_mode 2: bf16-plane copies of both
     char* winot6_arena = nullptr;
     std::map<const Param*, void*> winot6_of;
+    char* x3_arena = nullptr;                            // mfma_mode 2: bf16-plane copies of the direct 3x3 stride-1 weights (conv_x3.hip)
+    char* x3t_arena = nullptr;                           //              and of their flipped / transposed forms (data gradient)
+    std::map<const Param*, void*> x3t_of;
+    struct X3Batch { std::vector<X3WDesc> host; X3WDesc* dev = nullptr; long long max_elems = 0; };
+    X3Batch xb_fwd, xb_bwd;
+    void run_x3_batch(X3Batch& b, std::vector<X3WDesc>& descs);
     void refresh_wino(bool with_dgrad);
     // batched refresh: descriptor tables (host copy + device copy, re-uploaded only when a pointer changed)
     struct WinoBatch { std::vector<WinoWDesc> host; WinoWDesc* dev = nullptr; long long max_elems = 0; };
@@ -270,6 +277,7 @@ public:
     void forward_train_api(const float* X, bool on_dev, int B, int T, float* mask_out, bool mask_on_dev);
     void backward_api(const float* dmask, bool on_dev);
     bool graph_valid = false; int graph_B = 0, graph_T = 0; Tensor graph_f3; float* graph_mask = nullptr;
+    int64_t graph_gen = 0;                               // bumped by every vr_forward_train: the caller's backward names the graph it wants
     void param_arena(float** ptr, int64_t* numel) { *ptr = p_arena; *numel = (int64_t)p_floats; }
     void mark_params_dirty() { affine_dirty = true; }
     void adam_step_api(double lr, double b1, double b2, double eps, double grad_scale);

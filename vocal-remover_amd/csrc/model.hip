@@ -242,7 +242,7 @@ Model::~Model() {
     hipFree(wire_buf);
     if (stream) hipStreamSynchronize(stream);
     hipFree(p_arena); hipFree(b_arena); hipFree(d_fold);
-    hipFree(ws.base); hipFree(io.base); hipFree(gs.base); hipFree(wino_arena); hipFree(winot_arena); hipFree(wino6_arena); hipFree(winot6_arena); hipFree(wb_fwd.dev); hipFree(wb_bwd.dev); hipFree(wb_fwd6.dev); hipFree(wb_bwd6.dev); hipFree(aug_buf);
+    hipFree(ws.base); hipFree(io.base); hipFree(gs.base); hipFree(wino_arena); hipFree(winot_arena); hipFree(wino6_arena); hipFree(winot6_arena); hipFree(x3_arena); hipFree(x3t_arena); hipFree(xb_fwd.dev); hipFree(xb_bwd.dev); hipFree(wb_fwd.dev); hipFree(wb_bwd.dev); hipFree(wb_fwd6.dev); hipFree(wb_bwd6.dev); hipFree(aug_buf);
     hipFree(g_arena); hipFree(m_arena); hipFree(v_arena); hipFree(wt_arena); hipFree(d_flip); hipFree(dropout_buf);
     hipFree(plan.twiddle); hipFree(plan.window);
     for (Lane& l : lanes) {
@@ -333,6 +333,7 @@ void Model::fold_eval_affines() {
 }
 
 void Model::set_option(const std::string& name, int value) {
+    plan_peak = 0;                                           // kernel choice and scratch layout depend on the options: re-plan the next forward
     if (name == "train_winograd") train_wino = value != 0;
     else if (name == "serial_exec") serial = value != 0;     // every kernel on the handle's one stream (race detector of the tests)
     else if (name == "params_dirty") affine_dirty = true;    // the parameter arena was written from outside (vr_param_arena)
@@ -361,7 +362,38 @@ void Model::refresh_wino(bool with_dgrad) {
         run_wino_batch(wb_fwd, d, false);
     }
     auto cin_pad = [](const Conv* L) { return (L->Cin + 31) / 32 * 32; };
-    if (mfma_mode == 2) {
+    static const bool x3_on = !(getenv("VR_CONV_X3") && atoi(getenv("VR_CONV_X3")) == 0);
+    if (mfma_mode == 2 && x3_on) {
+        // split-bf16 copies of the DIRECT weights (conv_x3.hip takes every 3x3 stride-1 launch wide enough for its tiles)
+        if (!x3_arena) {
+            size_t total = 0;
+            for (Conv* L : wino_list) total += x3_weights_bytes(L->Cin, 9, L->CoutPad);
+            VR_HIP(hipMalloc(reinterpret_cast<void**>(&x3_arena), total ? total : 16));
+            size_t off = 0;
+            for (Conv* L : wino_list) { L->x3w = x3_arena + off; off += x3_weights_bytes(L->Cin, 9, L->CoutPad); }
+        }
+        {
+            std::vector<X3WDesc> d;
+            for (Conv* L : wino_list) d.push_back(X3WDesc{L->w->dev, L->x3w, L->Cin, 9, L->CoutPad});
+            run_x3_batch(xb_fwd, d);
+        }
+        if (with_dgrad) {
+            if (!x3t_arena) {
+                size_t total = 0;
+                for (Conv* L : wino_list) total += x3_weights_bytes(L->Cout, 9, cin_pad(L));
+                VR_HIP(hipMalloc(reinterpret_cast<void**>(&x3t_arena), total ? total : 16));
+                size_t off = 0;
+                for (Conv* L : wino_list) { x3t_of[L->w] = x3t_arena + off; off += x3_weights_bytes(L->Cout, 9, cin_pad(L)); }
+            }
+            std::vector<X3WDesc> d;
+            for (Conv* L : wino_list) {
+                auto it = wt_of.find(L->w);
+                if (it != wt_of.end()) d.push_back(X3WDesc{it->second, x3t_of[L->w], L->Cout, 9, cin_pad(L)});
+            }
+            run_x3_batch(xb_bwd, d);
+        }
+    }
+    if (mfma_mode == 2 && !x3_on) {
         // bf16-plane copies for the launches that can take the split kernel: the 64-cout Winograd variant only (conv_wino.hip)
         auto fwd6 = [](const Conv* L) { return L->CoutPad % 64 == 0; };
         auto bwd6 = [&](const Conv* L) { return cin_pad(L) % 64 == 0; };
@@ -407,6 +439,23 @@ void Model::refresh_wino(bool with_dgrad) {
         if (it != wt_of.end()) d.push_back(WinoWDesc{it->second, winot_of[L->w], L->Cout, cin_pad(L)});
     }
     run_wino_batch(wb_bwd, d, false);
+}
+
+void Model::run_x3_batch(X3Batch& b, std::vector<X3WDesc>& descs) {
+    if (descs.empty()) return;
+    bool same = b.dev && b.host.size() == descs.size();
+    for (size_t i = 0; same && i < descs.size(); ++i)
+        same = b.host[i].w == descs[i].w && b.host[i].o == descs[i].o && b.host[i].Cin == descs[i].Cin && b.host[i].CoutPad == descs[i].CoutPad;
+    if (!same) {
+        VR_HIP(hipStreamSynchronize(stream));
+        if (b.dev) VR_HIP(hipFree(b.dev));
+        VR_HIP(hipMalloc(reinterpret_cast<void**>(&b.dev), descs.size() * sizeof(X3WDesc)));
+        VR_HIP(hipMemcpy(b.dev, descs.data(), descs.size() * sizeof(X3WDesc), hipMemcpyHostToDevice));
+        b.host = descs;
+        b.max_elems = 0;
+        for (const X3WDesc& e : descs) b.max_elems = std::max(b.max_elems, (long long)((e.Cin + 7) / 8 * 8) * e.KK * e.CoutPad);
+    }
+    launch_x3_weights_batched(b.dev, (int)descs.size(), b.max_elems, stream);
 }
 
 // One launch for a whole descriptor table; the device copy is re-uploaded only when the table changed.
@@ -632,6 +681,7 @@ Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs_in, int N, cons
     if (fuse_epi) { a.epi = L.bn->affine; a.epi_slope = L.slope; }
     a.wino = (training && !train_wino) ? nullptr : L.wino;   // (null until the first refresh_wino())
     a.wino6 = (a.wino && mfma_mode == 2) ? L.wino6 : nullptr;
+    a.x3w = (mfma_mode == 2 && !(training && !train_wino)) ? L.x3w : nullptr;
     a.bf16 = mfma_mode;
     Tensor o;
     if (batch_as_h) {
@@ -1389,6 +1439,7 @@ void Model::debug_conv(const float* x, int N, int Cin, int H, int W, const float
     a.bf16 = mfma_mode;
     float* dwino = nullptr;
     void* dwino6 = nullptr;
+    void* dx3w = nullptr;
     if (want_wino) {
         VR_CHECK(KS == 3 && stride == 1 && dh == 1 && dw == 1, -2, "Winograd weights exist for 3x3 stride-1 convs only");
         VR_HIP(hipMalloc(&dwino, (size_t)Cin * 16 * CoutPad * 4));
@@ -1398,6 +1449,9 @@ void Model::debug_conv(const float* x, int N, int Cin, int H, int W, const float
             VR_HIP(hipMalloc(&dwino6, wino_weights6_bytes(Cin, CoutPad)));
             launch_wino_weights6(dw_, dwino6, Cin, CoutPad, stream);
             a.wino6 = dwino6;
+            VR_HIP(hipMalloc(&dx3w, x3_weights_bytes(Cin, 9, CoutPad)));
+            launch_x3_weights(dw_, dx3w, Cin, 9, CoutPad, stream);
+            a.x3w = dx3w;
         }
     }
     a.dst[0] = ConvDst{dout, (long long)Hout * Wout * Cout, (long long)Hout * Wout, (long long)Wout, 0};
@@ -1418,7 +1472,7 @@ void Model::debug_conv(const float* x, int N, int Cin, int H, int W, const float
             stats_out[2 * c] = (float)s1; stats_out[2 * c + 1] = (float)s2;
         }
     }
-    hipFree(dx); hipFree(dw_); hipFree(dout); hipFree(daff); hipFree(dbias); hipFree(dpart); hipFree(dwino); hipFree(dwino6);
+    hipFree(dx); hipFree(dw_); hipFree(dout); hipFree(daff); hipFree(dbias); hipFree(dpart); hipFree(dwino); hipFree(dwino6); hipFree(dx3w);
 }
 
 }  // namespace vr

@@ -204,6 +204,10 @@ void Model::bwd_conv(TapeRec& r) {
         auto it6 = winot6_of.find(L.w);
         d.wino6 = (d.wino && mfma_mode == 2 && it6 != winot6_of.end()) ? it6->second : nullptr;
     }
+    {
+        auto itx = x3t_of.find(L.w);
+        d.x3w = (!dry && train_wino && mfma_mode == 2 && itx != x3t_of.end()) ? itx->second : nullptr;
+    }
     d.bias = nullptr;
     d.bf16 = mfma_mode;
     d.Cout = L.Cin; d.CoutPad = round_up32(L.Cin);
@@ -252,7 +256,7 @@ void Model::bwd_conv(TapeRec& r) {
             {
                 ConvArgs k = c;
                 k.Hout = (f.Hin + 1) / 2; k.Wout = (f.Win + 1) / 2;
-                k.w = it->second; k.wino = nullptr; k.wino6 = nullptr;
+                k.w = it->second; k.wino = nullptr; k.wino6 = nullptr; k.x3w = nullptr;
                 k.s2_cls_stride = (long long)cls_stride; k.s2_H = f.Hin; k.s2_W = f.Win;
                 if (s2d_fused_eligible(k)) {
                     record_begin(0, 2.0 * N * (double)f.Hout * f.Wout * (double)L.Cout * L.Cin * L.KS * L.KS);
@@ -267,7 +271,7 @@ void Model::bwd_conv(TapeRec& r) {
                 ConvArgs k = c;
                 k.Hout = (f.Hin - ph + 1) / 2; k.Wout = (f.Win - pw + 1) / 2;
                 k.w = it->second + cls * cls_stride;
-                k.wino = nullptr; k.wino6 = nullptr;
+                k.wino = nullptr; k.wino6 = nullptr; k.x3w = nullptr;
                 int tm = 0;
                 for (int th = 0; th < 3; ++th)
                     for (int tw = 0; tw < 3; ++tw)
@@ -533,7 +537,7 @@ void Model::forward_train_api(const float* X, bool on_dev, int B, int T, float* 
     launch_head_sigmoid(graph_f3, out_w->dev, d, stream);
     VR_HIP(hipMemcpyAsync(mask_out, graph_mask, io_floats * sizeof(float), mask_on_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
     VR_HIP(hipStreamSynchronize(stream));
-    graph_valid = true; graph_B = B; graph_T = T;
+    graph_valid = true; graph_B = B; graph_T = T; ++graph_gen;
     affine_dirty = true;
 }
 

@@ -116,6 +116,7 @@ struct ConvArgs {
     const float* w;            // [Cin][KS*KS][CoutPad]  (K-major, cout contiguous)
     const float* wino;         // Winograd F(2x2,3x3) weights [Cin][16][CoutPad] (G g G^T), or null
     const void* wino6;         // the same weights as three bf16 planes [ceil(Cin/8)][16][3][CoutPad][8 channels] (bf16 == 2), or null
+    const void* x3w;           // the direct weights as three bf16 planes [ceil(Cin/8)][KS*KS][3][CoutPad][8 channels] (conv_x3.hip), or null
     const float* bias;         // [Cout] or null
     int Cout, CoutPad;
     ConvDst dst[3];

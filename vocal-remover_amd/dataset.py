@@ -208,65 +208,84 @@ class DeviceLoader(object):
             yield self.dataset.batch(idx)
 
 
-# ---- dataset preparation (lib/dataset.py:143-248): same file lists, cache layout and patch files as the reference ----
+# ---- dataset preparation: the on-disk contract of lib/dataset.py:143-248 ------------------------------------------------
+# What has to be identical to the reference is what lands on disk and what the lists contain: songs pair up by sorted file
+# name, the spectrogram cache is <audio dir>/sr{}_hl{}_nf{}/<song>.npy ([T, 2, bins] complex64, spec_utils.SpectrogramCache),
+# validation patches are cs{}_sr{}_hl{}_nf{}_of{}/<song>_p<j>.npz with keys X and y.  tests/test_cpu_frontend.py holds
+# these functions bit-equal to the reference's on a shared cache.
+AUDIO_SUFFIXES = frozenset(('.wav', '.m4a', '.mp3', '.mp4', '.flac'))
+
+
+def _audio_files(folder):
+    names = (n for n in os.listdir(folder) if os.path.splitext(n)[1] in AUDIO_SUFFIXES)
+    return sorted(os.path.join(folder, n) for n in names)
+
+
 def make_pair(mix_dir, inst_dir):
-    """lib/dataset.py:143-159."""
-    input_exts = ['.wav', '.m4a', '.mp3', '.mp4', '.flac']
-    X_list = sorted([os.path.join(mix_dir, fname) for fname in os.listdir(mix_dir) if os.path.splitext(fname)[1] in input_exts])
-    y_list = sorted([os.path.join(inst_dir, fname) for fname in os.listdir(inst_dir) if os.path.splitext(fname)[1] in input_exts])
-    return list(zip(X_list, y_list))
+    """Song i of the mixtures folder belongs to song i of the instruments folder, both in sorted order."""
+    return list(zip(_audio_files(mix_dir), _audio_files(inst_dir)))
+
+
+_SUBDIR_LAYOUT = {'train': ('training/mixtures', 'training/instruments'), 'val': ('validation/mixtures', 'validation/instruments')}
 
 
 def train_val_split(dataset_dir, split_mode, val_rate, val_filelist):
-    """lib/dataset.py:162-195 (uses the `random` module's stream exactly like the reference)."""
-    if split_mode == 'random':
-        filelist = make_pair(os.path.join(dataset_dir, 'mixtures'), os.path.join(dataset_dir, 'instruments'))
-        random.shuffle(filelist)
-        if len(val_filelist) == 0:
-            val_size = int(len(filelist) * val_rate)
-            train_filelist = filelist[:-val_size]
-            val_filelist = filelist[-val_size:]
-        else:
-            train_filelist = [pair for pair in filelist if list(pair) not in val_filelist]
-    elif split_mode == 'subdirs':
-        if len(val_filelist) != 0:
+    """(train pairs, validation pairs).  'random': ONE random.shuffle of the pair list (the caller seeds `random`, train.py:172),
+    the last int(n * val_rate) pairs validate -- or, with a given validation list, everything not on it trains.
+    'subdirs': the training/ and validation/ folders are the split."""
+    def under(rel):
+        return os.path.join(dataset_dir, rel)
+
+    if split_mode == 'subdirs':
+        if val_filelist:
             raise ValueError('`val_filelist` option is not available with `subdirs` mode')
-        train_filelist = make_pair(os.path.join(dataset_dir, 'training/mixtures'), os.path.join(dataset_dir, 'training/instruments'))
-        val_filelist = make_pair(os.path.join(dataset_dir, 'validation/mixtures'), os.path.join(dataset_dir, 'validation/instruments'))
-    return train_filelist, val_filelist
+        return make_pair(*map(under, _SUBDIR_LAYOUT['train'])), make_pair(*map(under, _SUBDIR_LAYOUT['val']))
+    if split_mode != 'random':
+        raise UnboundLocalError('unknown split_mode %r' % (split_mode,))      # (what the reference ends in for any other mode)
+    pairs = make_pair(under('mixtures'), under('instruments'))
+    random.shuffle(pairs)
+    if val_filelist:
+        held_out = [list(p) for p in val_filelist]
+        return [p for p in pairs if list(p) not in held_out], val_filelist
+    n_val = int(len(pairs) * val_rate)
+    cut = len(pairs) - n_val if n_val else 0        # (val_rate too small: slicing by -0 leaves the training list empty)
+    return pairs[:cut], pairs[cut:]
+
+
+def _song_peak(X, y):
+    return np.max([np.abs(X).max(), np.abs(y).max()])
 
 
 def make_training_set(filelist, sr, hop_length, n_fft):
-    """lib/dataset.py:208-217: [[X_cache_path, y_cache_path, coef], ...]."""
-    from . import spec_utils
-    ret = []
-    for X_path, y_path in filelist:
-        X, y, X_cache_path, y_cache_path = spec_utils.cache_or_load(X_path, y_path, sr, hop_length, n_fft)
-        coef = np.max([np.abs(X).max(), np.abs(y).max()])
-        ret.append([X_cache_path, y_cache_path, coef])
-    return ret
+    """One [mixture cache path, instrumental cache path, peak magnitude of the pair] row per song (VocalRemoverTrainingSet input)."""
+    from .spec_utils import SpectrogramCache
+    cache = SpectrogramCache(sr, hop_length, n_fft)
+    rows = []
+    for mix_path, inst_path in filelist:
+        X, y, mix_npy, inst_npy = cache.pair(mix_path, inst_path)
+        rows.append([mix_npy, inst_npy, _song_peak(X, y)])
+    return rows
 
 
 def make_validation_set(filelist, cropsize, sr, hop_length, n_fft, offset):
-    """lib/dataset.py:220-248: normalised, padded, overlapping cropsize-frame patches as .npz (keys X, y) in the
-    reference's directory `cs{}_sr{}_hl{}_nf{}_of{}` with the reference's file names."""
-    from . import spec_utils
-    patch_list = []
-    patch_dir = 'cs{}_sr{}_hl{}_nf{}_of{}'.format(cropsize, sr, hop_length, n_fft, offset)
-    os.makedirs(patch_dir, exist_ok=True)
-    for X_path, y_path in filelist:
-        basename = os.path.splitext(os.path.basename(X_path))[0]
-        X, y, _, _ = spec_utils.cache_or_load(X_path, y_path, sr, hop_length, n_fft)
-        coef = np.max([np.abs(X).max(), np.abs(y).max()])
-        X, y = X / coef, y / coef
-        l, r, roi_size = make_padding(X.shape[2], cropsize, offset)
-        X_pad = np.pad(X, ((0, 0), (0, 0), (l, r)), mode='constant')
-        y_pad = np.pad(y, ((0, 0), (0, 0), (l, r)), mode='constant')
-        len_dataset = int(np.ceil(X.shape[2] / roi_size))
-        for j in range(len_dataset):
-            outpath = os.path.join(patch_dir, '{}_p{}.npz'.format(basename, j))
-            start = j * roi_size
-            if not os.path.exists(outpath):
-                np.savez(outpath, X=X_pad[:, :, start:start + cropsize], y=y_pad[:, :, start:start + cropsize])
-            patch_list.append(outpath)
-    return patch_list
+    """Cuts every validation song into ceil(T / roi) windows of `cropsize` frames, `roi` apart, of the peak-normalised,
+    make_padding-padded spectrogram pair and stores each once as cs{}_sr{}_hl{}_nf{}_of{}/<song>_p<j>.npz; returns the paths."""
+    from .spec_utils import SpectrogramCache
+    cache = SpectrogramCache(sr, hop_length, n_fft)
+    out_dir = 'cs{}_sr{}_hl{}_nf{}_of{}'.format(cropsize, sr, hop_length, n_fft, offset)
+    os.makedirs(out_dir, exist_ok=True)
+    written = []
+    for mix_path, inst_path in filelist:
+        song = os.path.splitext(os.path.basename(mix_path))[0]
+        X, y, _, _ = cache.pair(mix_path, inst_path)
+        peak = _song_peak(X, y)
+        frames = X.shape[2]
+        left, right, roi = make_padding(frames, cropsize, offset)
+        widths = ((0, 0), (0, 0), (left, right))
+        padded = {'X': np.pad(X / peak, widths, mode='constant'), 'y': np.pad(y / peak, widths, mode='constant')}
+        for j in range(-(-frames // roi)):
+            path = os.path.join(out_dir, '{}_p{}.npz'.format(song, j))
+            if not os.path.exists(path):
+                np.savez(path, **{k: v[:, :, j * roi:j * roi + cropsize] for k, v in padded.items()})
+            written.append(path)
+    return written

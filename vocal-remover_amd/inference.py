@@ -93,6 +93,7 @@ def main(argv=None):
     p.add_argument('--cropsize', '-c', type=int, default=256)
     p.add_argument('--tta', '-t', action='store_true')
     p.add_argument('--postprocess', '-p', action='store_true')
+    p.add_argument('--output_image', '-I', action='store_true')      # accepted for command-line compatibility; no image is written
     p.add_argument('--output_dir', '-o', type=str, default="")
     args = p.parse_args(argv)
 

@@ -39,6 +39,7 @@ _SIGNATURES = {
     'vr_zero_grad': (ctypes.c_int, [ctypes.c_void_p]),
     'vr_get_adam_state': (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_int64, c_i64p]),
     'vr_set_adam_state': (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_int64, ctypes.c_int64]),
+    'vr_graph_generation': (ctypes.c_int, [ctypes.c_void_p, c_i64p, ctypes.POINTER(ctypes.c_int)]),
     'vr_get_grad': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_f32p, ctypes.c_int64]),
     'vr_set_dropout': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, c_f32p, ctypes.c_int]),
     'vr_grad_arena': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64)]),

@@ -104,13 +104,18 @@ class _ForwardTrain(torch.autograd.Function):
         if x.dim() != 4 or x.shape[1] != 2 or x.shape[2] != model.output_bin:
             raise ValueError('expected input [B, 2, %d, T], got %s' % (model.output_bin, tuple(x.shape)))
         on_dev = x.is_cuda
+        if on_dev and x.device.index != h.device:
+            raise RuntimeError('input is on %s but the model is on cuda:%d' % (x.device, h.device))
         xc = x.detach().to(torch.float32).contiguous()
         mask = torch.empty_like(xc)
-        if on_dev:
-            torch.cuda.current_stream(x.device).synchronize()
+        # a pending torch-side write to the parameter arena (torch.optim.Adam.step) must land before the library's own
+        # stream reads it -- also when X itself comes from the host
+        torch.cuda.current_stream(torch.device('cuda', h.device)).synchronize()
         native.check(native.lib().vr_forward_train(h.h, xc.data_ptr(), int(on_dev), int(xc.shape[0]), int(xc.shape[3]),
                                                    mask.data_ptr(), int(on_dev)))
         ctx.model = model
+        ctx.graph = model._graph_generation()[0]       # the handle keeps ONE graph: backward must name this one
+        ctx.handle_gen = model._handle_gen
         model._host_stale = True
         return mask
 
@@ -118,10 +123,14 @@ class _ForwardTrain(torch.autograd.Function):
     def backward(ctx, dmask):
         model = ctx.model
         h = model._need_handle()
+        gen, valid = model._graph_generation()
+        if ctx.handle_gen != model._handle_gen or gen != ctx.graph or not valid:
+            raise RuntimeError('backward through a CascadedNet forward whose graph is gone: the native handle keeps the graph of '
+                               'the LAST model(X) only (another forward / predict / validate call, a second backward or a '
+                               '.to(device) in between frees it)')
         on_dev = dmask.is_cuda
         d = dmask.detach().to(torch.float32).contiguous()
-        if on_dev:
-            torch.cuda.current_stream(d.device).synchronize()
+        torch.cuda.current_stream(torch.device('cuda', h.device)).synchronize()
         native.check(native.lib().vr_backward(h.h, d.data_ptr(), int(on_dev)))
         model._flat_parameter()                     # (re-)attach .grad to the arena view
         return None, None, None
@@ -146,6 +155,9 @@ class CascadedNet(object):
         self._spec = state_spec(n_fft, nout, nout_lstm)
         self._state = OrderedDict((k, _init_tensor(shape, init)) for k, shape, init in self._spec)
         self._handle = None
+        self._handle_gen = 0          # bumped whenever a native handle is created or closed
+        self._flat = self._flat_grad = None
+        self._flat_key = None
         self._device = torch.device('cpu')
         self._host_stale = False      # device weights newer than self._state (after training steps)
 
@@ -177,9 +189,9 @@ class CascadedNet(object):
             index = device.index if device.index is not None else torch.cuda.current_device()
             if self._handle is None or self._handle.device != index:
                 self._pull()
-                if self._handle is not None:
-                    self._handle.close()
+                self._drop_handle()
                 self._handle = native.Handle(index, self.n_fft, self.hop_length, self.nout, self.nout_lstm)
+                self._handle_gen += 1
                 self._device = torch.device('cuda', index)
                 self._push()
                 native.check(native.lib().vr_set_mode(self._handle.h, int(self.training)))
@@ -189,13 +201,32 @@ class CascadedNet(object):
                                                          None, 0))
         elif device.type == 'cpu':
             self._pull()
-            if self._handle is not None:
-                self._handle.close()
-                self._handle = None
+            self._drop_handle()
             self._device = device
         else:
             raise RuntimeError('CascadedNet (MI355X-native) supports cuda devices only, got %s' % device)
         return self
+
+    def _drop_handle(self):
+        """Close the native handle.  The flat Parameter / gradient views point into its arenas: detach them first, so that an
+        optimizer that still holds the Parameter steps an EMPTY tensor with no gradient instead of freed device memory."""
+        if self._handle is None:
+            return
+        if self._flat is not None:
+            self._flat.grad = None
+            self._flat.data = torch.empty(0)
+            self._flat._vr_model = None
+        self._flat = self._flat_grad = None
+        self._flat_key = None
+        self._handle.close()
+        self._handle = None
+        self._handle_gen += 1
+
+    def _graph_generation(self):
+        import ctypes
+        gen, valid = ctypes.c_int64(), ctypes.c_int()
+        native.check(native.lib().vr_graph_generation(self._need_handle().h, ctypes.byref(gen), ctypes.byref(valid)))
+        return int(gen.value), bool(valid.value)
 
     def cuda(self, index=None):
         return self.to(torch.device('cuda', index if index is not None else 0))
@@ -274,8 +305,9 @@ class CascadedNet(object):
         """ONE torch Parameter = a zero-copy view of the library's flat fp32 parameter arena (kernel layouts, padding
         included), `.grad` = a view of the gradient arena.  Element-wise optimizers (torch.optim.Adam of train.py:215,
         or vocal_remover_amd.train.Adam's fused kernel) do not care about the layout; padding has zero gradient."""
-        key = id(self._handle)
-        if getattr(self, '_flat_key', None) != key:
+        self._need_handle()
+        key = self._handle_gen                       # (not id(handle): CPython reuses ids of closed handles)
+        if self._flat_key != key:
             flat = torch.nn.Parameter(self._arena_tensor(native.lib().vr_param_arena), requires_grad=True)
             flat._vr_model = self
             self._flat, self._flat_grad, self._flat_key = flat, self._arena_tensor(native.lib().vr_grad_arena), key
@@ -290,7 +322,7 @@ class CascadedNet(object):
     def zero_grad(self, set_to_none=False):
         if self._handle is not None:
             native.check(native.lib().vr_zero_grad(self._handle.h))
-            if getattr(self, '_flat', None) is not None:
+            if self._flat is not None:
                 self._flat.grad = self._flat_grad                     # stays the arena view (never None)
 
     def train_step(self, X, y, accumulation_steps=1, return_mask=False):

@@ -58,55 +58,63 @@ def spectrogram_to_wave(spec, hop_length=1024):
     return wave[0] if mono else wave
 
 
-def align_wave_head_and_tail(a, b, sr):
-    """lib/spec_utils.py:96-119: trim both, cross-correlate the first 4 s of the mono sums, shift by the best lag,
-    cut to the common length.  The O(N^2) `np.correlate(..., 'full')` of the reference runs on the GPU (vr_xcorr_argmax)."""
+def _head_lag(a, b, sr, seconds=4):
+    """Lag (samples, positive = `a` starts late) at which the first `seconds` of the two stereo waves, summed to mono with the
+    mean removed, correlate best -- argmax of the full cross-correlation, evaluated on the GPU (vr_xcorr_argmax)."""
     import ctypes
-    a, _ = audio.trim(a)
-    b, _ = audio.trim(b)
-    a_mono = a[:, :sr * 4].sum(axis=0)
-    b_mono = b[:, :sr * 4].sum(axis=0)
-    a_mono = np.ascontiguousarray(a_mono - a_mono.mean(), dtype=np.float32)
-    b_mono = np.ascontiguousarray(b_mono - b_mono.mean(), dtype=np.float32)
-    offset = len(a_mono) - 1
-    best = ctypes.c_int64()
+    heads = []
+    for w in (a, b):
+        m = w[:, :sr * seconds].sum(axis=0)
+        heads.append(np.ascontiguousarray(m - m.mean(), dtype=np.float32))
     device = int(os.environ.get('VR_DEVICE', os.environ.get('LOCAL_RANK', '0')))
-    native.check(native.lib().vr_xcorr_argmax(device, native.np_ptr(a_mono), len(a_mono), native.np_ptr(b_mono), len(b_mono),
-                                              ctypes.byref(best)))
-    # np.correlate(a, b, 'full')[k] pairs a[n + k - (len(b) - 1)] with b[n]; the reference subtracts len(a) - 1
-    delay = int(best.value) - offset
-    if delay > 0:
-        a = a[:, delay:]
+    k = ctypes.c_int64()
+    native.check(native.lib().vr_xcorr_argmax(device, native.np_ptr(heads[0]), len(heads[0]), native.np_ptr(heads[1]), len(heads[1]),
+                                              ctypes.byref(k)))
+    return int(k.value) - (len(heads[0]) - 1)        # index of the 'full' correlation -> lag (the reference's own zero point)
+
+
+def align_wave_head_and_tail(a, b, sr):
+    """What lib/spec_utils.py:96-119 does to a (mixture, instrumental) pair before the STFT: strip leading / trailing silence
+    of each (librosa.effects.trim), drop the head of whichever starts late by the cross-correlation lag, cut both to the
+    shorter length."""
+    a, b = audio.trim(a)[0], audio.trim(b)[0]
+    lag = _head_lag(a, b, sr)
+    if lag > 0:
+        a = a[:, lag:]
     else:
-        b = b[:, np.abs(delay):]
-    if a.shape[1] < b.shape[1]:
-        b = b[:, :a.shape[1]]
-    else:
-        a = a[:, :b.shape[1]]
-    return a, b
+        b = b[:, -lag:]
+    n = min(a.shape[1], b.shape[1])
+    return a[:, :n], b[:, :n]
+
+
+class SpectrogramCache(object):
+    """The reference's spectrogram cache (lib/spec_utils.py:122-154) as an on-disk contract: the STFT of <dir>/<song>.<ext>
+    lives in <dir>/sr{sr}_hl{hop}_nf{n_fft}/<song>.npy as [T, 2, bins] complex64 (time-major, so that the training set can
+    seek-read cropsize rows, lib/dataset.py:15-46), and is computed from the ALIGNED pair, never from one file alone."""
+
+    def __init__(self, sr, hop_length, n_fft):
+        self.sr, self.hop_length, self.n_fft = sr, hop_length, n_fft
+        self.folder = 'sr{}_hl{}_nf{}'.format(sr, hop_length, n_fft)
+
+    def npy_path(self, audio_path):
+        folder = os.path.join(os.path.dirname(audio_path), self.folder)
+        os.makedirs(folder, exist_ok=True)
+        return os.path.join(folder, os.path.splitext(os.path.basename(audio_path))[0] + '.npy')
+
+    def pair(self, mix_path, inst_path):
+        """-> X, y [2, bins, T] complex64 and their .npy paths; decodes + aligns + transforms only on a cache miss."""
+        paths = [self.npy_path(mix_path), self.npy_path(inst_path)]
+        if all(os.path.exists(p) for p in paths):
+            specs = [np.load(p).transpose(1, 2, 0) for p in paths]
+        else:
+            waves = [audio.load(p, sr=self.sr, mono=False, dtype=np.float32, res_type='kaiser_fast')[0] for p in (mix_path, inst_path)]
+            specs = [wave_to_spectrogram(w, self.hop_length, self.n_fft) for w in align_wave_head_and_tail(waves[0], waves[1], self.sr)]
+            for p, spec in zip(paths, specs):
+                np.save(p, spec.transpose(2, 0, 1))
+        assert specs[0].shape == specs[1].shape
+        return specs[0], specs[1], paths[0], paths[1]
 
 
 def cache_or_load(mix_path, inst_path, sr, hop_length, n_fft):
-    """lib/spec_utils.py:122-154: same cache directories, file names and on-disk layout ([T, 2, bins] complex64 .npy)."""
-    mix_basename = os.path.splitext(os.path.basename(mix_path))[0]
-    inst_basename = os.path.splitext(os.path.basename(inst_path))[0]
-    cache_dir = 'sr{}_hl{}_nf{}'.format(sr, hop_length, n_fft)
-    mix_cache_dir = os.path.join(os.path.dirname(mix_path), cache_dir)
-    inst_cache_dir = os.path.join(os.path.dirname(inst_path), cache_dir)
-    os.makedirs(mix_cache_dir, exist_ok=True)
-    os.makedirs(inst_cache_dir, exist_ok=True)
-    mix_cache_path = os.path.join(mix_cache_dir, mix_basename + '.npy')
-    inst_cache_path = os.path.join(inst_cache_dir, inst_basename + '.npy')
-    if os.path.exists(mix_cache_path) and os.path.exists(inst_cache_path):
-        X = np.load(mix_cache_path).transpose(1, 2, 0)
-        y = np.load(inst_cache_path).transpose(1, 2, 0)
-    else:
-        X, _ = audio.load(mix_path, sr=sr, mono=False, dtype=np.float32, res_type='kaiser_fast')
-        y, _ = audio.load(inst_path, sr=sr, mono=False, dtype=np.float32, res_type='kaiser_fast')
-        X, y = align_wave_head_and_tail(X, y, sr)
-        X = wave_to_spectrogram(X, hop_length, n_fft)
-        y = wave_to_spectrogram(y, hop_length, n_fft)
-        np.save(mix_cache_path, X.transpose(2, 0, 1))
-        np.save(inst_cache_path, y.transpose(2, 0, 1))
-    assert X.shape == y.shape
-    return X, y, mix_cache_path, inst_cache_path
+    """The reference's entry point to the cache (lib/spec_utils.py:122): X, y, X_cache_path, y_cache_path."""
+    return SpectrogramCache(sr, hop_length, n_fft).pair(mix_path, inst_path)

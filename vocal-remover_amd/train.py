@@ -31,6 +31,7 @@ class Adam(torch.optim.Optimizer):
         if not refs:
             raise ValueError('pass model.parameters() of a vocal_remover_amd CascadedNet')
         self.model = refs[0]._vr_model
+        self._handle_gen = self.model._handle_gen      # the moments live in THIS native handle
         self.grad_scale = 1.0
         super().__init__(refs[:1], dict(lr=lr, betas=betas, eps=eps))
         self.model.set_option('adam_reset', 1)      # a new optimizer starts without moments, like torch.optim.Adam
@@ -39,6 +40,8 @@ class Adam(torch.optim.Optimizer):
         loss = closure() if closure is not None else None
         g = self.param_groups[0]
         h = self.model._need_handle()
+        if self._handle_gen != self.model._handle_gen:
+            raise RuntimeError('this optimizer belongs to a native handle that model.to(...) has closed since: build a new one')
         native.check(native.lib().vr_adam_step(h.h, float(g['lr']), float(g['betas'][0]), float(g['betas'][1]),
                                                float(g['eps']), float(self.grad_scale)))
         self.model._host_stale = True
