@@ -1,6 +1,10 @@
 """Worker of tests/test_gpu_dp.py: one data-parallel rank.  Launched by torch.distributed.run with a gloo process
-group; every rank opens its own handle on cuda:0 (ranks share the one GPU of the test box), the gradient bucket is
-staged through host memory for the all-reduce (Trainer backend 'staged').  Rank r trains on shard r of the batch."""
+group (host channel: the ncclUniqueId / the staged bucket).  argv: out_dir [backend [wire]]
+  backend 'staged' (default): every rank opens its handle on cuda:0 (ranks share the one GPU of the test box), the gradient
+                    bucket is staged through host memory for the all-reduce;
+  backend 'rccl':   rank r opens cuda:r and the library's own RCCL communicator carries the bucket over xGMI (fp32 or bf16
+                    wire) -- needs as many GPUs as ranks.
+Rank r trains on shard r of the batch."""
 import os
 import sys
 
@@ -16,6 +20,8 @@ from oracle import train_step, weights  # noqa: E402  (seeded inputs only)
 
 def main():
     out_dir = sys.argv[1]
+    backend = sys.argv[2] if len(sys.argv) > 2 else 'staged'
+    wire = sys.argv[3] if len(sys.argv) > 3 else 'fp32'
     dist.init_process_group('gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
     __graft_entry__.load_package()
@@ -25,10 +31,11 @@ def main():
     sd = weights.make_state_dict(11 if rank == 0 else 100 + rank, n_fft=n_fft, nout=nout, nout_lstm=nl)
     model = nets.CascadedNet(n_fft, n_fft // 2, nout, nl)
     model.load_state_dict(sd)
-    model.to(torch.device('cuda:0'))
-    tr = vtrain.Trainer(model, lr=1e-3, world_size=world, rank=rank, dropout=False, backend='staged')
+    dev = 'cuda:%d' % (rank if backend == 'rccl' else 0)
+    model.to(torch.device(dev))
+    tr = vtrain.Trainer(model, lr=1e-3, world_size=world, rank=rank, dropout=False, backend=backend, wire=wire)
     X, y = train_step.synth_batch(per * world, T=64, n_fft=n_fft, seed=7)
-    Xs, ys = X[rank * per:(rank + 1) * per].to('cuda:0'), y[rank * per:(rank + 1) * per].to('cuda:0')
+    Xs, ys = X[rank * per:(rank + 1) * per].to(dev), y[rank * per:(rank + 1) * per].to(dev)
     loss = model.train_step(Xs, ys, 1)
     tr.reduce()
     grads = {k: v.numpy() * tr.opt.grad_scale for k, v in model.grads().items()}

@@ -1,0 +1,211 @@
+"""GPU parity at the BENCHED train configuration (configs[3]: batch 16 x [2,1025,256]) -- VERDICT r2 "what's weak" 1, 2, 5.
+
+Kernel dispatch depends on the grid size (conv_wino.hip: 64-cout variant only from 600 workgroups; conv_dma.hip: cout tile and
+8x16 / 16x16 pixel tiles by workgroup count; conv_x3.hip: tile choice by workgroup count), so batch 16 launches variants that the
+batch-2 full-net test never reaches, and the train executor runs three streams.  Here:
+
+  * full net, batch 16: the three-stream executor vs serial_exec=1 (every kernel on ONE stream) and vs itself three times --
+    loss, mask and every gradient;
+  * single convs (forward, data gradient, weight gradient) at batch-16 grids on both sides of each dispatch threshold,
+    vs torch autograd, 2e-4 of the tensor's scale -- in the fp32-MFMA mode and in the split-bf16 mode;
+  * bf16-operand mode (configs[4] arithmetic) vs the fp32 mode, GPU vs GPU at batch 16 (no CPU oracle fits this batch);
+  * split-bf16 mode ("as exact as fp32") on inputs with subnormals, 2^+-100 scales and values on / next to bf16 rounding
+    boundaries, against an fp64 reference.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import train_step, weights
+
+pytestmark = pytest.mark.gpu
+
+HOP, N_FFT = 1024, 2048
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def full16(vr):
+    sd = weights.make_state_dict(1234)
+    model = vr.nets.CascadedNet(N_FFT, HOP, 32, 128)
+    model.load_state_dict(sd)
+    model.to(torch.device(DEV))
+    X, y = train_step.synth_batch(16, T=256, n_fft=N_FFT, seed=3)
+    masks = train_step.dropout_masks(16, seed=5, nout=32)
+    return model, sd, X.to(DEV), y.to(DEV), masks
+
+
+def _step(model, sd, X, y, masks, **options):
+    """One train step from the same weights: loss, mask, {key: gradient}."""
+    try:
+        model.load_state_dict(sd)
+        for k, v in options.items():
+            model.set_option(k, v)
+        model.train()
+        model.set_dropout_masks(masks)
+        model.zero_grad()
+        loss, mask = model.train_step(X, y, 1, return_mask=True)
+        return loss, mask.cpu(), model.grads()
+    finally:
+        model.set_dropout_masks(None)
+        for k in options:
+            model.set_option(k, 0)
+        model.eval()
+
+
+def _scale(t):
+    return float(t.abs().max()) + 1e-30
+
+
+def test_b16_train_step_three_streams_vs_one(vr, full16):
+    """Forward band fork, side-stream weight gradients and the third backward stream only reorder independent kernels (and the
+    order in which several consumers add into one activation gradient): against the same kernels on ONE stream every gradient
+    agrees to 1e-6 of its scale, and repeated concurrent runs agree with each other to the same bound."""
+    model, sd, X, y, masks = full16
+    for mode in (0, 2):
+        loss_s, mask_s, g_s = _step(model, sd, X, y, masks, serial_exec=1, mfma_mode=mode)
+        runs = [_step(model, sd, X, y, masks, mfma_mode=mode) for _ in range(3)]
+        worst, bit_equal = 0.0, True
+        for loss, mask, g in runs:
+            assert abs(loss - loss_s) <= 1e-6 * abs(loss_s), (mode, loss, loss_s)
+            assert float((mask - mask_s).abs().max()) <= 1e-6
+            for k in g_s:
+                e = float((g[k] - g_s[k]).abs().max()) / _scale(g_s[k])
+                worst = max(worst, e)
+                assert e <= 1e-6, (mode, k, e)
+                bit_equal = bit_equal and torch.equal(g[k], runs[0][2][k])
+        print('mfma_mode %d, batch 16: three-stream vs one-stream gradients worst %.2e of scale; run-to-run bit-equal: %s'
+              % (mode, worst, bit_equal))
+
+
+# N, Cin, H, W, Cout, ks, stride, dh, dw   -- workgroup counts on both sides of the dispatch thresholds at batch 16
+B16_CONVS = [
+    (16, 64, 160, 64, 64, 3, 1, 1, 1),      # 3x3 s1, 64 couts: 16*20*2 = 640 tiles -> 64-cout Winograd / x3<64,8>
+    (16, 64, 144, 64, 64, 3, 1, 1, 1),      # 576 tiles -> 32-cout Winograd variant
+    (16, 128, 64, 32, 128, 3, 1, 1, 1),     # 16*8*1 tiles x 2 cout tiles = 256 workgroups: halved cout tile
+    (16, 32, 128, 128, 32, 3, 1, 1, 1),     # 32 couts, 16-row tiles (>= 1024 workgroups) vs
+    (16, 32, 48, 64, 32, 3, 1, 1, 1),       # 8-row tiles
+    (16, 97, 64, 64, 32, 3, 1, 1, 1),       # decoder shape, Cin = 97 (partial channel chunk)
+    (16, 64, 128, 64, 192, 3, 2, 1, 1),     # stride 2: 16*8*1 tiles x 3 = 384 < 768 -> 32-cout tile; 16-wide? no: Wout = 32
+    (16, 64, 256, 64, 128, 3, 2, 1, 1),     # 16*16*1 x 2 = 512 -> 32; x (128/64) ...
+    (16, 64, 256, 128, 64, 3, 2, 1, 1),     # 16*16*2 x 1 = 512 -> 32-cout tile, Wout = 64
+    (16, 32, 512, 128, 64, 3, 2, 1, 1),     # 16*32*2 = 1024 >= 768 -> 64-cout stride-2 tile
+    (16, 128, 32, 16, 128, 3, 1, 1, 1),     # 1/16 resolution, 16 columns: 16*2*1*4 = 128 workgroups -> 8x16 tiles
+    (16, 256, 128, 16, 256, 3, 1, 4, 2),    # dilated, 16*8*1*8 = 1024 >= 800 -> 16x16 tiles
+    (16, 128, 32, 16, 128, 3, 1, 8, 4),     # dilated, 8x16 tiles
+    (16, 640, 32, 16, 128, 1, 1, 1, 1),     # 1x1 bottleneck, 16 columns
+    (16, 32, 256, 64, 16, 1, 1, 1, 1),      # 1x1 tail
+]
+
+
+@pytest.mark.parametrize('mode', [0, 2], ids=['fp32_mfma', 'split_bf16'])
+@pytest.mark.parametrize('case', B16_CONVS, ids=[str(c) for c in B16_CONVS])
+def test_b16_conv_dispatch_variants_vs_autograd(vr, full16, case, mode):
+    N, Cin, H, W, Cout, ks, stride, dh, dw = case
+    model = full16[0]
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = (torch.randn(Cout, Cin, ks, ks, generator=g) / (Cin * ks * ks) ** 0.5).requires_grad_(True)
+    a = x.clone().requires_grad_(True)
+    pad = (dh, dw) if ks == 3 else (0, 0)
+    torch.set_num_threads(16)
+    out = F.conv2d(a, w, None, stride, pad, (dh, dw))
+    dz = torch.randn(out.shape, generator=g)
+    out.backward(dz)
+    nat = vr.native
+    xn, wn, dzn = x.numpy(), w.detach().numpy(), dz.numpy()
+    got = np.empty(tuple(out.shape), np.float32)
+    dx = np.empty(tuple(x.shape), np.float32)
+    dwt = np.empty(tuple(w.shape), np.float32)
+    try:
+        model.set_option('mfma_mode', mode)
+        flags = 2 if (ks == 3 and stride == 1 and dh == 1) else 0          # transformed / split weights for the 3x3 stride-1 kernels
+        nat.check(nat.lib().vr_debug_conv2d(model._handle.h, nat.np_ptr(xn), N, Cin, H, W, nat.np_ptr(wn), Cout, ks, stride, dh, dw,
+                                            flags, None, ctypes.c_float(1.0), None, nat.np_ptr(got), None))
+        nat.check(nat.lib().vr_debug_conv2d_backward(model._handle.h, nat.np_ptr(xn), N, Cin, H, W, nat.np_ptr(wn), Cout, ks, stride,
+                                                     dh, dw, 0, None, ctypes.c_float(1.0), nat.np_ptr(dzn), nat.np_ptr(dx),
+                                                     nat.np_ptr(dwt)))
+    finally:
+        model.set_option('mfma_mode', 0)
+    ef = float(np.abs(got - out.detach().numpy()).max() / out.detach().abs().max())
+    ex = float(np.abs(dx - a.grad.numpy()).max() / a.grad.abs().max())
+    ew = float(np.abs(dwt - w.grad.numpy()).max() / w.grad.abs().max())
+    assert ef < 2e-4 and ex < 2e-4 and ew < 2e-4, 'forward %.2e dgrad %.2e wgrad %.2e' % (ef, ex, ew)
+
+
+def test_b16_bf16_mode_vs_fp32_mode(vr, full16):
+    """configs[4] arithmetic (bf16 MFMA operands in the Winograd / GEMM kernels, fp32 everything else) against the fp32 mode on
+    the SAME GPU at the benched batch: with 16 x 256 x 1025 samples per BatchNorm channel the batch statistics are stable, so
+    the bar is a real one: loss within 1e-3 relative, per-tensor gradient cosine >= 0.99 and norm ratio within 2 % for every
+    tensor of at least 64 elements."""
+    model, sd, X, y, masks = full16
+    loss0, mask0, g0 = _step(model, sd, X, y, masks)
+    loss1, mask1, g1 = _step(model, sd, X, y, masks, mfma_bf16=1)
+    rows = []
+    for k in g0:
+        if g0[k].numel() < 64 or float(g0[k].norm()) == 0.0:
+            continue
+        a, b = g0[k].double().flatten(), g1[k].double().flatten()
+        rows.append((float(a @ b / (a.norm() * b.norm() + 1e-300)), float(b.norm() / a.norm()), k))
+    rows.sort()
+    print('\n'.join('%-60s cos %.5f  |g| ratio %.4f' % (k, c, r) for c, r, k in rows[:12]))
+    cos = np.array([r[0] for r in rows])
+    ratio = np.array([r[1] for r in rows])
+    print('bf16 mode vs fp32 mode, batch 16: loss %.8f vs %.8f; cosine min %.4f median %.5f; |g| ratio %.4f .. %.4f; mask max-abs %.2e'
+          % (loss1, loss0, cos.min(), np.median(cos), ratio.min(), ratio.max(), float((mask1 - mask0).abs().max())))
+    assert abs(loss1 - loss0) <= 1e-3 * abs(loss0)
+    assert float((mask1 - mask0).abs().max()) <= 2e-2
+    assert cos.min() >= 0.99, rows[0]
+    assert ratio.min() >= 0.98 and ratio.max() <= 1.02
+
+
+SPECIAL = ['subnormal', 'scale_2^-100', 'scale_2^+100', 'bf16_boundaries']
+
+
+@pytest.mark.parametrize('kind', SPECIAL)
+@pytest.mark.parametrize('shape', [(2, 40, 32, 64, 64), (2, 24, 40, 64, 32)], ids=['64couts', '32couts'])
+def test_split_bf16_mode_is_fp32_exact_on_special_values(vr, full16, kind, shape):
+    """x = bf16(x) + bf16(x - x1) + (x - x1 - x2) must stay exact where rounding to bf16 is delicate: fp32 subnormals (the third
+    plane underflows bf16's range only below 2^-133), huge / tiny scales, values exactly on a bf16 grid point, half way between
+    two, and one fp32 ulp to either side.  Error vs fp64 at most 1.5x the fp32-MFMA kernel's + 1e-7 of the output scale."""
+    N, Cin, H, W, Cout = shape
+    model = full16[0]
+    rng = np.random.default_rng(7)
+    x = (rng.standard_normal((N, Cin, H, W)) * np.exp(rng.standard_normal((N, Cin, H, W)))).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9.0)).astype(np.float32)
+    if kind == 'subnormal':
+        sel = rng.random(x.shape) < 0.3
+        x[sel] = (rng.standard_normal(int(sel.sum())) * 2.0 ** -140).astype(np.float32)
+    elif kind == 'scale_2^-100':
+        x = (x * np.float32(2.0 ** -100)).astype(np.float32)
+    elif kind == 'scale_2^+100':
+        x = (x * np.float32(2.0 ** 100)).astype(np.float32)
+    else:
+        u = x.view(np.uint32).copy()
+        r = rng.integers(0, 5, size=x.shape)
+        u = np.where(r == 0, u & 0xffff0000, u)                       # exact bf16 value
+        u = np.where(r == 1, (u & 0xffff0000) | 0x8000, u)            # half way between two bf16 values (ties-to-even case)
+        u = np.where(r == 2, (u & 0xffff0000) | 0x7fff, u)            # one ulp below the tie
+        u = np.where(r == 3, (u & 0xffff0000) | 0x8001, u)            # one ulp above the tie
+        x = u.astype(np.uint32).view(np.float32)
+        wu = w.view(np.uint32).copy()
+        w = np.where(rng.random(w.shape) < 0.5, (wu & 0xffffff00) | 0x80, wu).astype(np.uint32).view(np.float32)
+    want = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), None, 1, 1).numpy()
+    scale = float(np.abs(want).max())
+    nat = vr.native
+    errs = {}
+    for mode in (0, 2):
+        got = np.empty(want.shape, np.float32)
+        try:
+            model.set_option('mfma_mode', mode)
+            nat.check(nat.lib().vr_debug_conv2d(model._handle.h, nat.np_ptr(x), N, Cin, H, W, nat.np_ptr(w), Cout, 3, 1, 1, 1, 2, None,
+                                                ctypes.c_float(1.0), None, nat.np_ptr(got), None))
+        finally:
+            model.set_option('mfma_mode', 0)
+        assert np.isfinite(got).all()
+        errs[mode] = float(np.abs(got.astype(np.float64) - want).max()) / scale
+    print('%s %s: max error / scale  fp32 MFMA %.3e  split-bf16 %.3e' % (kind, shape, errs[0], errs[2]))
+    assert errs[2] <= 1.5 * errs[0] + 1e-7

@@ -80,8 +80,17 @@ def test_reference_train_epoch_statements_run_through_the_autograd_shim(vr):
     # a forward in between frees the graph: backward must fail loudly, not corrupt
     pred = b(Xd[:2])
     b.eval(); b(Xd[:2]); b.train()
-    with pytest.raises(ValueError):
+    with pytest.raises(RuntimeError):
         (pred.sum()).backward()
+    # two forwards, then backward through the FIRST: the handle holds the second one's graph -- must fail loudly,
+    # while the second one's backward still works
+    b.zero_grad()
+    pred1 = b(Xd[:2])
+    pred2 = b(Xd[2:4])
+    with pytest.raises(RuntimeError):
+        (pred1.sum()).backward()
+    (pred2.sum()).backward()
+    assert any(float(v.abs().max()) > 0 for v in b.grads(keys={'stg3_full_band_net.dec1.conv1.conv.0.weight'}).values())
 
 
 def test_resample_kaiser_fast_vs_restatement_and_properties(vr):

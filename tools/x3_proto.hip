@@ -14,7 +14,8 @@
 
 using namespace vr;
 
-struct SrcDef { int C; int halo; };     // a source tensor of C channels stored with `halo` extra columns/rows around it (strided view)
+struct SrcDef { int C; int halo; int up = 0; };     // a source of C channels stored with `halo` extra columns/rows around it (strided view);
+                                                   // up: stored at half resolution, seen through the bilinear x2 (align_corners=True)
 
 __global__ void ref_points_kernel(const ConvArgs a, const int* __restrict__ idx, int npts, double* __restrict__ ref) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -34,7 +35,19 @@ __global__ void ref_points_kernel(const ConvArgs a, const int* __restrict__ idx,
             for (int kx = 0; kx < 3; ++kx) {
                 const int hi = ho + ky - 1, wi = wo + kx - 1;
                 if (hi < 0 || hi >= a.Hin || wi < 0 || wi >= a.Win) continue;
-                s += (double)base[(long long)hi * c.sH + wi] * (double)a.w[((long long)ci * 9 + ky * 3 + kx) * a.CoutPad + co];
+                double v;
+                if (c.up) {
+                    const double hr = (double)(c.H - 1) / (double)(2 * c.H - 1) * hi, wr = (double)(c.W - 1) / (double)(2 * c.W - 1) * wi;
+                    const int h1 = (int)hr, w1 = (int)wr;
+                    const int h1p = h1 < c.H - 1, w1p = w1 < c.W - 1;
+                    const double hl = hr - h1, wl = wr - w1;
+                    const float* r0 = base + (long long)h1 * c.sH;
+                    const float* r1 = r0 + (long long)h1p * c.sH;
+                    v = (1 - hl) * ((1 - wl) * r0[w1] + wl * r0[w1 + w1p]) + hl * ((1 - wl) * r1[w1] + wl * r1[w1 + w1p]);
+                } else {
+                    v = (double)base[(long long)hi * c.sH + wi];
+                }
+                s += v * (double)a.w[((long long)ci * 9 + ky * 3 + kx) * a.CoutPad + co];
             }
     }
     if (a.bias) s += a.bias[co];
@@ -81,8 +94,9 @@ static void run_shape(const char* name, int N, std::vector<SrcDef> srcs, int Cou
     a.nsrc = (int)srcs.size();
     std::vector<float*> bufs;
     for (int i = 0; i < a.nsrc; ++i) {
-        const int halo = srcs[i].halo, C = srcs[i].C;
-        const int Hs = H + 2 * halo, Ws = W + 2 * halo;
+        const int halo = srcs[i].halo, C = srcs[i].C, up = srcs[i].up;
+        const int Hl = up ? H / 2 : H, Wl = up ? W / 2 : W;
+        const int Hs = Hl + 2 * halo, Ws = Wl + 2 * halo;
         std::vector<float> hx((size_t)N * C * Hs * Ws);
         for (auto& v : hx) {
             float x = nd(rng) * std::exp(nd(rng)) * xscale;
@@ -102,7 +116,8 @@ static void run_shape(const char* name, int N, std::vector<SrcDef> srcs, int Cou
         ConvSrc c{};
         c.p = dx + (size_t)halo * Ws + halo;
         c.sH = Ws; c.sC = (long long)Hs * Ws; c.sN = c.sC * C;
-        c.C = C; c.H = H; c.W = W; c.hsplit = 1 << 30; c.slope = 1.f;
+        c.C = C; c.H = Hl; c.W = Wl; c.hsplit = 1 << 30; c.slope = 1.f; c.up = up;
+        c.rh = (float)(Hl - 1) / (float)(2 * Hl - 1); c.rw = (float)(Wl - 1) / (float)(2 * Wl - 1);
         a.src[i] = c;
     }
     a.c1 = a.nsrc >= 2 ? srcs[0].C : Cin;
@@ -156,10 +171,12 @@ static void run_shape(const char* name, int N, std::vector<SrcDef> srcs, int Cou
         VR_HIP(hipMemset(dout, 0xff, nout * 4));
         const double us = time_us([&] { x3_launch_conv(b, t, 0); }, 5);
         printf(" x3<%d,%d> %7.1f us %6.1f TF", t.MT, t.TH, us, flops / us * 1e-6);
-        if (dbg == 0) check("x3"); else printf(" |");
+        if ((dbg & 15) == 0) check("x3"); else printf(" |");
     }
     // ---- Winograd fp32 ----
-    if (dbg == 0) {
+    bool has_up = false;
+    for (auto& sd : srcs) has_up = has_up || sd.up;
+    if (dbg == 0 && !has_up) {
         float* dwino = dalloc((size_t)Cin * 16 * CoutPad);
         launch_wino_weights(dw, dwino, Cin, CoutPad, 0);
         ConvArgs b = a;
@@ -192,14 +209,26 @@ static void run_shape(const char* name, int N, std::vector<SrcDef> srcs, int Cou
 int main(int argc, char** argv) {
     const int quick = argc > 1 ? atoi(argv[1]) : 0;
     try {
+        if (quick != 2) {
         // correctness: odd sizes, partial tiles, partial channel chunks, three strided sources
         run_shape("small odd", 1, {{10, 0}}, 20, 37, 48, 1.f, 0);
         run_shape("3 strided sources 13+8+1", 2, {{13, 2}, {8, 0}, {1, 3}}, 40, 50, 70, 1.f, 0);
+        run_shape("3 aligned strided sources", 2, {{13, 4}, {8, 0}, {1, 8}}, 40, 50, 72, 1.f, 0);
         run_shape("64ch single tile", 1, {{64, 0}}, 64, 8, 32, 1.f, 0);
+        run_shape("upsampled 16 + skip 8", 2, {{16, 0, 1}, {8, 0}}, 32, 40, 64, 1.f, 0);
+        run_shape("upsampled 13 (strided) + up 1 + skip 10", 2, {{13, 2, 1}, {1, 0, 1}, {10, 3}}, 40, 36, 96, 1.f, 0);
+        run_shape("upsampled only, odd tiles", 1, {{24, 0, 1}}, 64, 20, 40, 1.f, 0);
         run_shape("scale 2^-100", 1, {{24, 0}}, 32, 32, 64, std::ldexp(1.f, -100), 0);
         run_shape("scale 2^+100", 1, {{24, 0}}, 32, 32, 64, std::ldexp(1.f, 100), 0);
         run_shape("subnormal / bf16-boundary inputs", 1, {{24, 0}}, 64, 32, 64, 1.f, 1);
-        if (quick) return 0;
+        }
+        if (quick == 1) return 0;
+        if (quick == 2) {                                   // profiling run (rocprofv3 --pmc): the two layers the tuning is about
+            run_shape("stg3 dec1 97->32 @1024x256", 6, {{64, 0}, {32, 0}, {1, 0}}, 32, 1024, 256, 1.f, 0);
+            run_shape("stg3 dec2 192->64 @512x128", 6, {{128, 0}, {64, 0}}, 64, 512, 128, 1.f, 0);
+            run_shape("dbg1 dec1", 6, {{64, 0}, {32, 0}, {1, 0}}, 32, 1024, 256, 1.f, 0, 1);
+            return 0;
+        }
         // the stride-1 3x3 layers of one inference lane (N = 6 crops) -- SURVEY.md §8(a-detail)
         run_shape("stg3 dec1 97->32 @1024x256", 6, {{64, 0}, {32, 0}, {1, 0}}, 32, 1024, 256, 1.f, 0);
         run_shape("stg3 dec2 192->64 @512x128", 6, {{128, 0}, {64, 0}}, 64, 512, 128, 1.f, 0);
@@ -211,13 +240,23 @@ int main(int argc, char** argv) {
         run_shape("stg2l dec1 97->32 @512x256", 6, {{64, 0}, {32, 0}, {1, 0}}, 32, 512, 256, 1.f, 0);
         run_shape("stg2l dec2 192->64 @256x128", 6, {{128, 0}, {64, 0}}, 64, 256, 128, 1.f, 0);
         run_shape("stg1l dec1 49->16 @512x256", 6, {{32, 0}, {16, 0}, {1, 0}}, 16, 512, 256, 1.f, 0);
-        // ablations of the x3 kernel on two layers: 2 = no MFMA, 3 = no split pass, 1 = no pixel loads, 4 = no epilogue
-        for (int dbg : {2, 3, 1, 4}) {
+        // the same decoder layers with the x2 upsample fused (eval mode: the upsampled tensor is never materialised)
+        run_shape("stg3 dec1 up64+up1+32 ->32 @1024x256", 6, {{64, 0, 1}, {1, 0, 1}, {32, 0}}, 32, 1024, 256, 1.f, 0);
+        run_shape("stg3 dec2 up128+64 ->64 @512x128", 6, {{128, 0, 1}, {64, 0}}, 64, 512, 128, 1.f, 0);
+        run_shape("stg3 dec3 up192+128 ->128 @256x64", 6, {{192, 0, 1}, {128, 0}}, 128, 256, 64, 1.f, 0);
+        // ablations of the x3 kernel on two layers: 16 = tiles interleaved over the XCDs (the other kernels' mapping) instead of a
+        // contiguous range per XCD; 2 = no MFMA, 3 = no split pass, 1 = no pixel loads, 4 = no epilogue
+        for (int dbg : {16, 3, 1, 4}) {
             char nm[64];
             snprintf(nm, sizeof nm, "dbg%d stg3 dec1 97->32", dbg);
             run_shape(nm, 6, {{64, 0}, {32, 0}, {1, 0}}, 32, 1024, 256, 1.f, 0, dbg);
             snprintf(nm, sizeof nm, "dbg%d stg3 dec2 192->64", dbg);
             run_shape(nm, 6, {{128, 0}, {64, 0}}, 64, 512, 128, 1.f, 0, dbg);
+            if (dbg == 16) {
+                run_shape("dbg16 stg3 dec3 320->128", 6, {{192, 0}, {128, 0}}, 128, 256, 64, 1.f, 0, dbg);
+                run_shape("dbg16 stg3 enc2b 64->64", 6, {{64, 0}}, 64, 512, 128, 1.f, 0, dbg);
+                run_shape("dbg16 stg2l dec1 97->32", 6, {{64, 0}, {32, 0}, {1, 0}}, 32, 512, 256, 1.f, 0, dbg);
+            }
         }
     } catch (const vr::Error& e) {
         printf("ERROR %d: %s\n", e.code, e.what());

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, 4) void conv_thin_kernel(const ConvArgs a) {
 
     const int id = blockIdx.x;
     const int xcd = id & 7;
-    const int pt = (id >> 3) * 8 + xcd;
+    const int pt = (a.dbg & 16) ? (id >> 3) * 8 + xcd : xcd * ((a.npt + 7) >> 3) + (id >> 3);      // contiguous tile range per XCD (conv_x3.hip)
     if (pt >= a.npt) return;
     const int tiles_per_img = a.tiles_h * a.tiles_w;
     const int n = pt / tiles_per_img;

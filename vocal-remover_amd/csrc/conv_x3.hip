@@ -21,18 +21,29 @@
 // The epilogue is conv_dma.hip's (same 32x32 accumulator layout): bias, folded BatchNorm + activation (eval), up to three
 // destination segments, BatchNorm partial sums (training).
 #include <cstdlib>
+#include <type_traits>
 
 #include "conv_stage.h"
 #include "kernels.h"
 #include "lds_dma.h"
 
-#ifndef X3_VARIANT
-#define X3_VARIANT 0
-#endif
-
 namespace vr {
 
-__device__ float x3_buffer_load(i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+// The pixel loads are inline asm and their waits are placed by hand: hipcc's wait-count pass loses the issue order of loads that
+// cross a loop back edge / uniform branches and then waits for (nearly) everything, i.e. also for the loads issued for the chunk
+// after next -- the prefetch depth the register sets pay for.
+__device__ __forceinline__ float x3_load(i32x4 rsrc, int voff) {
+    float v;
+    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(rsrc) : "memory");
+    return v;
+}
+// s_waitcnt vmcnt(N) that the uses of the eight registers cannot be scheduled across
+template <int N>
+__device__ __forceinline__ void x3_wait8(float (&r)[8]) {
+    asm volatile("s_waitcnt vmcnt(%8)"
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+                 : "n"(N) : "memory");
+}
 
 template <int MT, int TH>
 struct X3Cfg {
@@ -46,9 +57,16 @@ struct X3Cfg {
     static constexpr int NWP = KK * 3 * MT;                      // 16-byte weight operands per chunk
     static constexpr int W_BYTES = NWP * 16;
     static constexpr int NWPASS = (NWP + 255) / 256;
-    static constexpr int LDS_BYTES = P_BYTES + 2 * W_BYTES;
+    // fused bilinear x2 (lib/layers.py:52): the low-resolution pixels under the halo tile, [8 ch][LROWS][LW] fp32
+    static constexpr int LROWS = TH / 2 + 3, LW = 20, LSLOT = LROWS * LW;
+    static constexpr int L_OFF = P_BYTES + 2 * W_BYTES;
+    static constexpr int L_BYTES = CK * LSLOT * 4;
+    static constexpr int LDS_BYTES = L_OFF + L_BYTES;
     static constexpr int OCC = 3 * LDS_BYTES <= 160 * 1024 ? 3 : 2;   // workgroups per CU the register budget must allow
-    static_assert(TH % 4 == 0 && MT % 32 == 0 && LDS_BYTES <= 80 * 1024, "tile");
+    // vector-memory operations a wave issues per chunk: 8 * NPASS pixel loads (always, also beyond Cin: empty descriptor), and at
+    // least NWMIN weight DMAs (the last wave-instruction of the weight slab may be empty for some waves)
+    static constexpr int NXL = 8 * NPASS, NWMIN = (NWP / 64) / 4;
+    static_assert(TH % 4 == 0 && MT % 32 == 0 && LDS_BYTES <= 80 * 1024 && 2 * NXL + NWMIN < 64 && NXL <= 30 && LSLOT <= 256, "tile");
 };
 
 template <int MT, int TH>
@@ -63,7 +81,12 @@ __global__ __launch_bounds__(256, (X3Cfg<MT, TH>::OCC)) void conv_x3_kernel(cons
     const int xcd = id & 7;
     const int rr = id >> 3;
     const int ct = rr % a.nct;
-    const int pt = (rr / a.nct) * 8 + xcd;
+    // Block b runs on XCD b % 8 (observed dispatch order).  Every XCD walks its OWN contiguous, row-major range of pixel tiles, so
+    // the tiles resident on an XCD at any time are neighbours: the 128-byte lines that horizontally adjacent tiles share (a 34-pixel
+    // halo row spans three lines) and the halo rows of vertically adjacent ones come from the XCD's L2 (measured: -8 % on the
+    // full-resolution layers against tiles interleaved over the XCDs, VR_CONV_DBG=16).
+    const int per_xcd = (a.npt + 7) >> 3;
+    const int pt = (a.dbg & 16) ? (rr / a.nct) * 8 + xcd : xcd * per_xcd + rr / a.nct;
     if (pt >= a.npt) return;
     const int tiles_per_img = a.tiles_h * a.tiles_w;
     const int n = pt / tiles_per_img;
@@ -76,8 +99,9 @@ __global__ __launch_bounds__(256, (X3Cfg<MT, TH>::OCC)) void conv_x3_kernel(cons
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nchunk = (a.Cin + 7) >> 3;
     const unsigned lds0 = (unsigned)(size_t)smem_x3;
+    const int dbg = a.dbg & 15;
 
-    // ---- this thread's pixels of the halo tile: byte offset in the source = hrow * (4 * sH) + wcol4 (2^31: padding) ----
+    // ---- this thread's pixels of the halo tile: byte offset in a channel plane = hrow * (4 * sH) + wcol4 (2^31: padding) ----
     unsigned hrow[NPASS], wcol4[NPASS];
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
@@ -88,6 +112,33 @@ __global__ __launch_bounds__(256, (X3Cfg<MT, TH>::OCC)) void conv_x3_kernel(cons
         hrow[p] = ok ? (unsigned)hi : 0u;
         wcol4[p] = ok ? (unsigned)(wi * 4) : 0x80000000u;
     }
+    // ---- sources that arrive through the decoder's bilinear x2 (align_corners=True; eval: the upsample is not materialised):
+    // this thread's low-resolution pixel of the staging tile, and for each of its halo pixels the position inside that tile
+    // and the two interpolation weights (upsampled sources share their geometry: model.hip) ----
+    const ConvSrc& us = a.src[0].up ? a.src[0] : (a.src[1].up ? a.src[1] : a.src[2]);
+    const bool any_up = a.src[0].up | a.src[1].up | a.src[2].up;
+    int lrow = 0, lcol4 = 0;                       // low-res pixel this thread fetches (byte column; 2^31: none)
+    int lidx[NPASS];
+    float lh[NPASS], lw_[NPASS];
+    if (any_up) {
+        const int lr0 = (int)(us.rh * (float)(h0 > 0 ? h0 - 1 : 0)), lc0 = (int)(us.rw * (float)(w0 > 0 ? w0 - 1 : 0));
+        const int lr = lr0 + tid / Cfg::LW, lc = lc0 + tid % Cfg::LW;
+        const bool lok = tid < Cfg::LSLOT && lr < us.H && lc < us.W;
+        lrow = lok ? lr : 0;
+        lcol4 = lok ? lc * 4 : (int)0x80000000u;
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const int s = p * 256 + tid;
+            const int r = s / PW, c = s - r * PW;
+            const int hi = h0 - 1 + r, wi = w0 - 1 + c;
+            const bool ok = s < NSLOT && hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win;
+            const float h1r = us.rh * (float)(ok ? hi : 0), w1r = us.rw * (float)(ok ? wi : 0);
+            const int h1 = (int)h1r, w1 = (int)w1r;
+            lidx[p] = ok ? ((h1 - lr0) * Cfg::LW + (w1 - lc0)) * 4 : -1;
+            lh[p] = h1r - (float)h1;
+            lw_[p] = w1r - (float)w1;
+        }
+    }
     // ---- weight operands: LDS order [tap][plane][m], source x3w[chunk][(tap * 3 + plane) * CoutPad + co0 + m] ----
     unsigned woff[NWPASS];
 #pragma unroll
@@ -97,8 +148,7 @@ __global__ __launch_bounds__(256, (X3Cfg<MT, TH>::OCC)) void conv_x3_kernel(cons
         woff[i] = (unsigned)((tp * a.CoutPad + m) * 16);
     }
     const long long wchunk_bytes = (long long)KK * 3 * a.CoutPad * 16;
-
-    auto issue_w = [&](int k) {
+    auto issue_w = [&](int k) {                                    // the weight DMA of chunk k: NWPASS wave-instructions
         const char* wb = static_cast<const char*>(a.x3w) + k * wchunk_bytes + (long long)co0 * 16;
         const i32x4 wr = make_rsrc(reinterpret_cast<const float*>(wb), (unsigned)(wchunk_bytes - (long long)co0 * 16));
         const unsigned ws_b = lds0 + (unsigned)(Cfg::P_BYTES + (k & 1) * Cfg::W_BYTES);
@@ -115,43 +165,81 @@ __global__ __launch_bounds__(256, (X3Cfg<MT, TH>::OCC)) void conv_x3_kernel(cons
     long long xsC = a.src[0].sC;
     unsigned xsH4 = (unsigned)a.src[0].sH * 4u;
     int xend = a.c1, xsi = 0;
-    int xvo[NPASS];                                            // byte offset of this thread's pixels in a channel plane of the current source
+    bool xup = a.src[0].up != 0;
+    unsigned upm[2] = {0u, 0u};                                    // per pixel-register set: which of the 8 channels are upsampled sources
+    int xvo[NPASS];                                                // byte offset of this thread's pixels in a channel plane of the current source
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) xvo[p] = (int)(hrow[p] * xsH4 + wcol4[p]);
-    float xr[NPASS][8];
     auto next_source = [&]() {
         ++xsi;
-        if (xsi == 1) { xp = a.src[1].p + (long long)n * a.src[1].sN; xsC = a.src[1].sC; xsH4 = (unsigned)a.src[1].sH * 4u; xend = a.c2; }
-        else { xp = a.src[2].p + (long long)n * a.src[2].sN; xsC = a.src[2].sC; xsH4 = (unsigned)a.src[2].sH * 4u; xend = 1 << 30; }
+        if (xsi == 1) { xp = a.src[1].p + (long long)n * a.src[1].sN; xsC = a.src[1].sC; xsH4 = (unsigned)a.src[1].sH * 4u; xend = a.c2; xup = a.src[1].up != 0; }
+        else { xp = a.src[2].p + (long long)n * a.src[2].sN; xsC = a.src[2].sC; xsH4 = (unsigned)a.src[2].sH * 4u; xend = 1 << 30; xup = a.src[2].up != 0; }
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) xvo[p] = (int)(hrow[p] * xsH4 + wcol4[p]);
     };
-    // NB straight-line code on purpose (no loop, the loads unconditional): hipcc's wait-count pass flushes vmcnt in front of
-    // any inner loop and protects conditionally loaded registers with a vmcnt(0) at the top of the next chunk -- right behind
-    // the weight DMA just issued, i.e. one exposed DMA latency per chunk (measured on the first version: 680 vs 406 us).
-    auto load_x = [&](int k) {
+    // Pixel registers of two chunks: the loads of chunk k+2 are issued during the multiply phase of chunk k and consumed at the end of
+    // the multiply phase of chunk k+1 -- one multiply phase (1.4 us of matrix-pipe time) is shorter than the loaded memory latency.
+    // Every chunk issues the SAME number of loads (channels beyond Cin read through an empty descriptor), so the hand-placed
+    // s_waitcnt counts are compile-time constants.
+    float xr[2][NPASS][8];
+    auto load_channel = [&](int k, int cl, auto par) {
+        constexpr int PAR = decltype(par)::value;
+        const int ci = k * 8 + cl;                                // wave-uniform
+        const bool live = ci < a.Cin && dbg != 1;
+        if (live && ci >= xend) next_source();                    // (a source may be a single channel: two steps at most)
+        if (live && ci >= xend) next_source();
+        const i32x4 xs = make_rsrc(xp, live ? 0x7FFFFFF0u : 0u);
+        const bool up = live && xup;
+        if (cl == 0) upm[PAR] = 0u;
+        upm[PAR] |= (up ? 1u : 0u) << cl;
+        // an upsampled source: ONE low-resolution pixel per thread (register set 0 of the channel); the other sets load nothing
+        xr[PAR][0][cl] = x3_load(xs, up ? (int)((unsigned)lrow * xsH4) + lcol4 : xvo[0]);
+        const i32x4 xs1 = make_rsrc(xp, (live && !up) ? 0x7FFFFFF0u : 0u);
 #pragma unroll
-        for (int cl = 0; cl < 8; ++cl) {
-            const int ci = k * 8 + cl;                            // wave-uniform
-            const bool live = ci < a.Cin && a.dbg != 1;
-            if (live && ci >= xend) next_source();                // (a source may be a single channel: two steps at most)
-            if (live && ci >= xend) next_source();
-            const i32x4 xs = make_rsrc(xp, live ? 0x7FFFFFF0u : 0u);      // channels beyond Cin: an empty descriptor reads zeros
-#pragma unroll
-            for (int p = 0; p < NPASS; ++p) xr[p][cl] = x3_buffer_load(xs, xvo[p], 0, 0);
-            if (live) xp += xsC;
-        }
+        for (int p = 1; p < NPASS; ++p) xr[PAR][p][cl] = x3_load(xs1, xvo[p]);
+        if (live) xp += xsC;
     };
-    auto convert = [&]() {
+    // the pixel registers of set PAR have landed when at most NEWER younger vector-memory operations are outstanding
+    auto wait_pixels = [&](auto par, auto newer) {
+        constexpr int PAR = decltype(par)::value, NEWER = decltype(newer)::value;
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) x3_wait8<NEWER>(xr[PAR][p]);
+    };
+    // low-resolution pixels of the upsampled channels -> LDS (before the barrier in front of the split pass)
+    auto stage_lowres = [&](auto par) {
+        constexpr int PAR = decltype(par)::value;
+        if (upm[PAR] == 0u) return;
+        float* lq = reinterpret_cast<float*>(smem_x3 + Cfg::L_OFF) + tid;
+#pragma unroll
+        for (int cl = 0; cl < 8; ++cl)
+            if (((upm[PAR] >> cl) & 1u) && tid < Cfg::LSLOT) lq[cl * Cfg::LSLOT] = xr[PAR][0][cl];
+    };
+    auto convert = [&](auto par) {
+        constexpr int PAR = decltype(par)::value;
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
             const int s = p * 256 + tid;
             if ((p + 1) * 256 <= NSLOT || s < NSLOT) {
                 vr_i32x4 ph, pm, pl;
+                if (upm[PAR] != 0u) {
+                    // torch's bilinear, align_corners=True (pointwise.hip: upsample2x_kernel): the +1 neighbours are read even at the
+                    // last row / column, where their weight is exactly 0 and the staging tile holds zeros
+                    const char* lq = smem_x3 + Cfg::L_OFF + (lidx[p] >= 0 ? lidx[p] : 0);
+                    const float h1l = lh[p], h0l = 1.f - h1l, w1l = lw_[p], w0l = 1.f - w1l;
+#pragma unroll
+                    for (int cl = 0; cl < 8; ++cl) {
+                        if ((upm[PAR] >> cl) & 1u) {
+                            const float* q = reinterpret_cast<const float*>(lq + cl * Cfg::LSLOT * 4);
+                            const float v00 = q[0], v01 = q[1], v10 = q[Cfg::LW], v11 = q[Cfg::LW + 1];
+                            const float v = h0l * (w0l * v00 + w1l * v01) + h1l * (w0l * v10 + w1l * v11);
+                            xr[PAR][p][cl] = lidx[p] >= 0 ? v : 0.f;
+                        }
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     int h, m, l;
-                    split3_pair(xr[p][2 * j], xr[p][2 * j + 1], h, m, l);
+                    split3_pair(xr[PAR][p][2 * j], xr[PAR][p][2 * j + 1], h, m, l);
                     ph[j] = h; pm[j] = m; pl[j] = l;
                 }
                 char* q = Pb + s * 16;
@@ -177,21 +265,30 @@ __global__ __launch_bounds__(256, (X3Cfg<MT, TH>::OCC)) void conv_x3_kernel(cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    // NB the waits in front of the chunk barriers are the BUILTIN, not inline asm: hipcc's wait-count pass must see that the
-    // pixel loads have retired, or it protects their registers (written again by the next load_x) with a vmcnt(0) of its own --
-    // placed right behind the weight DMA of the next chunk, i.e. one exposed DMA latency per chunk (measured: 680 -> 406 us).
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    // prologue: pixels of chunk 0 -> P, weights of chunk 0 and pixels of chunk 1 in flight
+#pragma unroll
+    for (int cl = 0; cl < 8; ++cl) load_channel(0, cl, P0{});
     issue_w(0);
-    load_x(0);
-    convert();
-    __builtin_amdgcn_s_waitcnt(0x0070);                      // vmcnt(0) lgkmcnt(0)
+#pragma unroll
+    for (int cl = 0; cl < 8; ++cl) load_channel(1, cl, P1{});
+    wait_pixels(P0{}, std::integral_constant<int, Cfg::NXL + Cfg::NWMIN>{});      // chunk 0's pixels (weights and chunk 1 stay in flight)
+    if (any_up) {
+        stage_lowres(P0{});
+        lds_barrier();
+    }
+    convert(P0{});
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(Cfg::NXL) : "memory");   // weights of chunk 0 landed; chunk 1's pixels stay in flight
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    for (int k = 0; k < nchunk; ++k) {
+    // one chunk: multiply P(k) x W(k) while the weights of chunk k+1 and the pixels of chunk k+2 arrive; then split chunk k+1 into P
+    auto chunk = [&](int k, auto par) {
+        constexpr int PAR = decltype(par)::value;                 // k & 1: the pixel registers chunk k came from (free again)
         const bool more = k + 1 < nchunk;
-        if (more) { issue_w(k + 1); load_x(k + 1); }
-        if (a.dbg != 2) {
-            const char* Wb = smem_x3 + Cfg::P_BYTES + (k & 1) * Cfg::W_BYTES;
+        {
+            const char* Wb = smem_x3 + Cfg::P_BYTES + PAR * Cfg::W_BYTES;
             vr_bf16x8 A[2][3][WM], B[2][2][WN];
             // operand reads of tap t, in the order the MFMA groups consume them: part 0 = [a3|a1] + [b1|b3], part 1 = [a2|a2] + [b1|b2],
             // part 2 = [a1|a1]
@@ -221,13 +318,17 @@ __global__ __launch_bounds__(256, (X3Cfg<MT, TH>::OCC)) void conv_x3_kernel(cons
 #pragma unroll
             for (int t = 0; t < KK; ++t) {
                 const int cur = t & 1;
-#if X3_VARIANT == 1
-                // the reads of tap t+1 go out in three bursts between the three MFMA groups of tap t
+                // the operand reads of tap t+1 go out in three bursts between the three MFMA groups of tap t; the vector-memory work
+                // for the coming chunks rides behind the first groups of taps 0..4 (weights first: they are needed one chunk earlier)
                 if (t + 1 < KK) read_part(t + 1, cur ^ 1, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_group(cur, 2, 1);
                 __builtin_amdgcn_sched_barrier(0);
                 if (t + 1 < KK) read_part(t + 1, cur ^ 1, 1);
+                if (more) {
+                    if (t == 0) issue_w(k + 1);
+                    if (t >= 1 && t <= 4) { load_channel(k + 2, 2 * t - 2, par); load_channel(k + 2, 2 * t - 1, par); }
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_group(cur, 1, 0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -235,27 +336,27 @@ __global__ __launch_bounds__(256, (X3Cfg<MT, TH>::OCC)) void conv_x3_kernel(cons
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_group(cur, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-#else
-                if (t + 1 < KK) { read_part(t + 1, cur ^ 1, 0); read_part(t + 1, cur ^ 1, 1); read_part(t + 1, cur ^ 1, 2); }
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_group(cur, 2, 1);
-                mfma_group(cur, 1, 0);
-                mfma_group(cur, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-#endif
             }
         }
         if (more) {
-            lds_barrier();                                   // every wave has read P(k)
-            if (a.dbg != 3) convert();                        // (the compiler waits for the pixel loads; the weight DMA was issued before them)
-            __builtin_amdgcn_s_waitcnt(0x0070);              // vmcnt(0) lgkmcnt(0)
-            __builtin_amdgcn_s_barrier();                    // P(k+1) complete, W(k+1) landed
+            using Q = std::integral_constant<int, PAR ^ 1>;
+            // outstanding, oldest first: chunk k+1's pixels | weights of chunk k+1 | chunk k+2's pixels
+            wait_pixels(Q{}, std::integral_constant<int, Cfg::NXL + Cfg::NWMIN>{});
+            if (any_up) stage_lowres(Q{});
+            lds_barrier();                                       // every wave has read P(k); the low-resolution tile of chunk k+1 is in LDS
+            if (dbg != 3) convert(Q{});
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(Cfg::NXL) : "memory");   // weights of chunk k+1 landed
+            __builtin_amdgcn_s_barrier();                        // P(k+1) complete
             asm volatile("" ::: "memory");
         }
+    };
+    for (int k = 0; k < nchunk; k += 2) {
+        chunk(k, P0{});
+        if (k + 1 < nchunk) chunk(k + 1, P1{});
     }
 
     // ---------------- epilogue (as conv_dma.hip): bias, (eval) BatchNorm + activation, up to three destination segments -------
-    if (a.dbg == 4) return;
+    if (dbg == 4) return;
     if (a.d1 >= a.CoutPad) {
         long long offn[WN];
         bool okn[WN];
@@ -423,10 +524,15 @@ bool x3_pick(const ConvArgs& a, const ConvShape& s, X3Tile* t) {
     if (!enabled || !a.x3w || a.tapmask) return false;
     if (!(s.KS == 3 && s.stride == 1 && s.dil_h == 1 && s.dil_w == 1)) return false;
     if (a.pad_h != 1 || a.pad_w != 1 || a.Wout < 32) return false;
+    const ConvSrc* u = nullptr;
     for (int i = 0; i < a.nsrc; ++i) {
         const ConvSrc& c = a.src[i];
-        if (c.aff0 || c.aff1 || c.post || c.up || c.zins || c.slope != 1.f || c.W != a.Win) return false;
+        if (c.aff0 || c.aff1 || c.post || c.zins || c.slope != 1.f || (c.up ? 2 * c.W : c.W) != a.Win) return false;
         if ((long long)c.H * (c.sH > 0 ? c.sH : 1) * 4 >= 0x7FFFFFF0LL) return false;
+        if (c.up) {                                          // fused bilinear x2: one interpolation geometry per launch
+            if (u && (u->H != c.H || u->W != c.W)) return false;
+            u = &c;
+        }
     }
     int MT = (a.CoutPad % 64 == 0) ? 64 : 32;
     int TH = 8;

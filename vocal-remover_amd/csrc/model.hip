@@ -673,6 +673,30 @@ Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs_in, int N, cons
     }
     ConvArgs a;
     build_fwd_args(L, srcs, N, batch_as_h, a);
+    if (!training) {
+        // fused-upsample sources are for conv_x3.hip only: anything else gets the materialised tensor after all
+        bool any_up = false;
+        for (const SrcSpec& sp : srcs) any_up = any_up || sp.up;
+        if (any_up) {
+            ConvArgs probe = a;
+            probe.x3w = (mfma_mode == 2) ? L.x3w : nullptr;
+            probe.bf16 = mfma_mode;
+            X3Tile xt;
+            if (!x3_pick(probe, ConvShape{L.KS, L.stride, L.dh, L.dw}, &xt)) {
+                for (SrcSpec& sp : srcs) {
+                    if (!sp.up) continue;
+                    const Tensor& t = sp.t;
+                    Tensor u;
+                    u.N = t.N; u.C = t.C; u.H = 2 * t.H; u.W = 2 * t.W;
+                    u.sH = u.W; u.sC = (long long)u.H * u.W; u.sN = u.sC * u.C; u.slope = 1.f;
+                    u.p = ws.allocf((size_t)u.N * u.C * u.H * u.W);
+                    if (!dry) launch_upsample2x(t, u.p, stream);
+                    sp = SrcSpec{u};
+                }
+                build_fwd_args(L, srcs, N, batch_as_h, a);
+            }
+        }
+    }
     a.bias = bias;
     // Eval: the folded BatchNorm + activation go into the conv's epilogue, so the stored tensor is the
     // final activation and its consumers load it with no arithmetic (conv_dma.hip).  Training keeps
@@ -816,6 +840,17 @@ Tensor Model::run_lstm(LSTMMod& M, const Tensor& h) {
 // loader; eval materialises it once (HBM-bound, small) so the conv reads a plain tensor by LDS-DMA.
 Model::SrcSpec Model::upsampled(const Tensor& t) {
     if (training) {
+        SrcSpec s{t};
+        s.up = true;
+        return s;
+    }
+    // Eval, split-bf16 mode: conv_x3.hip interpolates while it splits the pixels into bf16 planes, so the full-resolution decoder
+    // layers read the LOW-resolution tensor (a quarter of the bytes) and nothing is materialised.  Measured per layer (tools/
+    // x3_proto.hip): it pays from 512 x 128 output pixels on (dec1, stage-3 dec2); below, the interpolation VALU of the many-channel
+    // layers costs more than the HBM-bound upsample pass.
+    static const bool fuse_on = !(getenv("VR_X3_FUSE_UP") && atoi(getenv("VR_X3_FUSE_UP")) == 0);
+    static const bool x3_on = !(getenv("VR_CONV_X3") && atoi(getenv("VR_CONV_X3")) == 0);
+    if (fuse_on && x3_on && mfma_mode == 2 && 4LL * t.H * t.W >= 65536 && 2 * t.W >= 32 && !t.aff0 && !t.aff1 && !t.post && t.slope == 1.f) {
         SrcSpec s{t};
         s.up = true;
         return s;

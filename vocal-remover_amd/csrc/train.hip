@@ -723,6 +723,19 @@ void Model::debug_conv_bwd(const float* x, int N, int Cin, int H, int W, const f
     VR_HIP(hipMalloc(&dfd, sizeof(FlipDesc)));
     VR_HIP(hipMemcpy(dfd, &fd, sizeof(FlipDesc), hipMemcpyHostToDevice));
     launch_flip_transpose(dfd, 1, stream);
+    // 3x3 stride-1: the data gradient takes the same kernels as in a train step (Winograd / split-bf16 direct over the flipped weights)
+    float* dwinot = nullptr;
+    void* dx3t = nullptr;
+    if (KS == 3 && stride == 1 && dh == 1 && dw == 1 && train_wino) {
+        VR_HIP(hipMalloc(&dwinot, (size_t)Cout * 16 * CinPad * sizeof(float)));
+        launch_wino_weights(dwt, dwinot, Cout, CinPad, stream);
+        winot_of[&P] = dwinot;
+        if (mfma_mode == 2) {
+            VR_HIP(hipMalloc(&dx3t, x3_weights_bytes(Cout, 9, CinPad)));
+            launch_x3_weights(dwt, dx3t, Cout, 9, CinPad, stream);
+            x3t_of[&P] = dx3t;
+        }
+    }
     float* ds2w = nullptr;                    // stride-2 3x3: also exercise the parity-class data gradient
     if (KS == 3 && stride == 2 && dh == 1 && dw == 1) {
         VR_HIP(hipMalloc(&ds2w, (size_t)4 * Cout * 9 * CinPad * sizeof(float)));
@@ -759,7 +772,9 @@ void Model::debug_conv_bwd(const float* x, int N, int Cin, int H, int W, const f
             for (int k = 0; k < KK; ++k) dw_out[((size_t)co * Cin + ci) * KK + k] = gk[((size_t)ci * KK + k) * CoutPad + co];
     wt_of.erase(&P);
     s2w_of.erase(&P);
-    hipFree(ds2w);
+    winot_of.erase(&P);
+    x3t_of.erase(&P);
+    hipFree(ds2w); hipFree(dwinot); hipFree(dx3t);
     hipFree(dx); hipFree(dgx); hipFree(dwk); hipFree(dwt); hipFree(dgw); hipFree(dzd); hipFree(daff); hipFree(dfd);
 }
 
