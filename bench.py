@@ -13,9 +13,14 @@ between barriers after the headline region:
     "tta"    configs[2]: the same song through Separator.separate_tta (23 crops)
     "train"  configs[3]: the train.py step (fwd + L1 + bwd [+ RCCL all-reduce of the flat gradient bucket over the N
              ranks] + Adam), batch 16 x [2,1025,256] per GPU
-plus `roofline` (dominant kernel family = the fp32-MFMA convs: algorithmic FLOPs / HIP-event time per launch, summed
-over the launches of one step; HBM traffic per launch from the committed rocprofv3 PMC passes) and `cpu_baseline`
-(the CPU oracle -- a port of the reference's path, kind "port" -- timed on this box's host cores, N=1 only).
+plus `roofline` (dominant kernel family = the MFMA convs: algorithmic FLOPs / HIP-event time per launch, summed over the
+launches of ONE EXTRA step run with every kernel serialised on one stream -- not the timed steps, which overlap lanes and
+streams; HBM traffic per launch from the committed rocprofv3 PMC passes) and `cpu_baseline` (the CPU oracle -- a port of
+the reference's path, kind "port" -- timed on this box's host cores, N=1 only).
+
+Arithmetic: fp32 throughout; the 3x3 stride-1 convolutions form every fp32 product from six bf16 products of three-way
+split operands on the bf16 matrix pipe (mfma_mode 2, the library default: error against fp64 = an fp32 direct
+convolution's).  `fp32_mfma` carries the same workloads with v_mfma_f32_32x32x2_f32 everywhere (mfma_mode 0).
 
 `python bench.py --gpus N` without a torch.distributed environment launches its own N ranks
 (python -m torch.distributed.run); under the driver's launcher it just reads RANK / WORLD_SIZE.
@@ -102,11 +107,36 @@ def cpu_baseline_infer(sd, frames=1292):
                       'reference path, torch CPU) STFT->separate(batch 4)->iSTFT x2, %.1f s wall' % (T, L / SR, -(-T // 128) + 1, dt)}
 
 
-def cpu_baseline_train(sd, B=2):
-    """CPU oracle train step (fwd + L1 + bwd + Adam) on a bounded sample: batch 2 of the same crop shape."""
+def _host_memory_gb():
+    """Memory this process may use: MemAvailable capped by the cgroup limit."""
+    avail = None
+    try:
+        for line in open('/proc/meminfo'):
+            if line.startswith('MemAvailable:'):
+                avail = int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    try:
+        lim = open('/sys/fs/cgroup/memory.max').read().strip()
+        if lim != 'max':
+            cur = int(open('/sys/fs/cgroup/memory.current').read().strip())
+            left = (int(lim) - cur) / 1e9
+            avail = left if avail is None else min(avail, left)
+    except (OSError, ValueError):
+        pass
+    return avail if avail is not None else 8.0
+
+
+def cpu_baseline_train(sd, want_batch=16):
+    """CPU oracle train step (fwd + L1 + bwd + Adam) at the largest batch <= the GPU's that fits the host's memory
+    (autograd keeps ~2.6 GB of activations per sample in fp32) and a ~30 s budget."""
     from oracle import train_step as ots, weights as ow
     cores = usable_cores()
     torch.set_num_threads(cores)
+    mem = _host_memory_gb()
+    B = want_batch
+    while B > 2 and (3.0 * B + 4.0 > 0.7 * mem or B > 8):     # 8 samples ~ 25 s on 16 cores: the bounded-sample budget
+        B //= 2
     sd = ow.clone_state_dict(sd)
     X, y = ots.synth_batch(B, T=CROP, n_fft=N_FFT, seed=0)
     opt = ots.Adam(lr=1e-3)
@@ -115,16 +145,19 @@ def cpu_baseline_train(sd, B=2):
     opt.step(sd, grads)
     dt = time.perf_counter() - t0
     return {'value': B * CROP / dt, 'unit': 'spectrogram-frames/sec', 'cores': cores, 'kind': 'port',
-            'sample': 'one oracle train step (port: autograd over the restated net + restated Adam) at batch %d x '
-                      '[2,1025,256] (the GPU runs batch 16), %.1f s wall' % (B, dt)}
+            'sample': 'one oracle train step (port: autograd over the restated net + restated Adam) at batch %d x [2,1025,256] '
+                      '-- the largest power of two <= 16 that fits %.0f GB of host memory and the ~30 s sample budget (the GPU runs '
+                      'batch %d) -- %.1f s wall' % (B, mem, want_batch, dt)}
 
 
-CONV_FAMILY_INFER = ('conv family on the fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4): conv_wino_kernel<*> (Winograd F(2x2,3x3), the '
-                     '3x3 stride-1 layers) + conv_dma_kernel<*> (direct implicit GEMM: stride-2, dilated, 1x1) + conv_thin_kernel<*> '
-                     '(3x3 layers with <= 16 output channels)')
-CONV_FAMILY_TRAIN = ('conv family on the fp32 MFMA: conv_wino_kernel<*> / conv_dma_kernel<*> / conv_thin_kernel<*> (forward + data '
-                     'gradients over materialised plain tensors; stride-2 data gradient = conv_dma_s2d_kernel, the four parity '
-                     'classes in one launch) + wgrad_*_kernel<*> (weight gradient: Winograd F(3x3,2x2), LDS-DMA GEMMs)')
+CONV_FAMILY_INFER = ('conv family: conv_x3_kernel<*> (3x3 stride-1 layers, direct, fp32 products from six bf16 products on '
+                     'v_mfma_f32_32x32x16_bf16; decoder bilinear x2 fused) + conv_dma_kernel<*> (stride-2, dilated, 1x1, 16-wide: fp32 MFMA) '
+                     '+ conv_thin_kernel<*> (<= 16 output channels, fp32 MFMA); mfma_mode 0: conv_wino_kernel<*> (Winograd F(2x2,3x3), '
+                     'fp32 MFMA) instead of conv_x3')
+CONV_FAMILY_TRAIN = ('conv family: conv_x3_kernel<*> / conv_dma_kernel<*> / conv_thin_kernel<*> (forward + data gradients over '
+                     'materialised plain tensors; stride-2 data gradient = conv_dma_s2d_kernel) + wgrad_*_kernel<*> (weight gradient on '
+                     'the fp32 MFMA: Winograd F(3x3,2x2), LDS-DMA GEMMs)')
+SPLIT_DTYPE = 'f32 (3x3 stride-1 convs: bf16x3 split operands, six bf16 products per fp32 product, fp32 accumulate; rest: fp32 MFMA / VALU)'
 
 
 def self_launch(args):
@@ -198,11 +231,15 @@ def main():
             step()
         barrier()
         dt = time.perf_counter() - t0
+        timed.per_rank = [dt]
         if world > 1:
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
+            every = [torch.zeros_like(tt) for _ in range(world)]
+            dist.all_gather(every, tt)
+            timed.per_rank = [float(t.item()) for t in every]
+            dt = max(timed.per_rank)
         return dt
+    timed.per_rank = []
 
     def conv_profile(step):
         """HIP events (on the library's stream) around every MFMA-conv launch of one step, kernels serialised."""
@@ -222,6 +259,12 @@ def main():
             src = 'profiles/' + pmc_name
         return {'bound': 'mfma', 'kernel': kernel, 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
+                'source': 'ONE EXTRA step after the timed region, every launch serialised on one stream and bracketed by HIP events on '
+                          'the library\'s stream (the timed steps overlap 2 lanes x 2 streams, so kernel_ms_per_step can exceed ms_per_step)',
+                'peak_note': 'peak = fp32 MFMA (v_mfma_f32_32x32x2_f32 = the fp32 vector rate).  In mfma_mode 2 the 3x3 stride-1 convs run '
+                             'on the bf16 pipe instead: 2500 TFLOP/s dense / 6 products = %.0f fp32-equivalent TFLOP/s at 2.4 GHz -- the '
+                             'chip clocks down to ~1.7 GHz under that load (profiles/README.md); their MFMA-pipe busy fraction is in '
+                             'profiles/r03_infer_sq_pmc.md' % (2500.0 / 6.0),
                 'traffic_unit': 'HBM bytes per launch (mean over the conv launches of a step; rocprofv3 FETCH_SIZE x2 '
                                 'gfx950 correction + WRITE_SIZE, %s)' % src,
                 'algorithmic_bytes_per_launch': cby / max(cn, 1),
@@ -245,7 +288,7 @@ def main():
         crops = crops_tta if tta else crops_plain
         res = {'frames_per_sec': world * T * args.steps / dt, 'ms_per_step': dt / args.steps * 1e3,
                'computed_frames_per_sec': world * crops * CROP * args.steps / dt, 'crops_per_step_per_gpu': crops,
-               'frames_per_step_per_gpu': T}
+               'frames_per_step_per_gpu': T, 'ms_per_step_per_rank': [t / args.steps * 1e3 for t in timed.per_rank]}
         return res, step
 
     def run_train(bf16=False):
@@ -261,12 +304,29 @@ def main():
         X = X.to(dev)
         step = lambda: trainer.step(X, y)                                   # noqa: E731
         dt = timed(step, args.steps, args.warmup)
+        per_rank = [t / args.steps * 1e3 for t in timed.per_rank]
+        allreduce_ms = None
+        if world > 1:
+            # the exchange alone, outside the timed region: the gradient bucket of the last step, summed three more times with a
+            # device sync on both sides (vr_allreduce_grads runs on the library's own stream)
+            ts = []
+            for _ in range(3):
+                barrier()
+                t0 = time.perf_counter()
+                trainer.reduce()
+                torch.cuda.synchronize()          # device-wide: also the library's own (non-blocking) stream
+                ts.append((time.perf_counter() - t0) * 1e3)
+            tt = torch.tensor([min(ts)], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            allreduce_ms = float(tt.item())
+            net.zero_grad()
         res = {'frames_per_sec': world * B * CROP * args.steps / dt, 'ms_per_step': dt / args.steps * 1e3,
+               'ms_per_step_per_rank': per_rank, 'allreduce_ms': allreduce_ms,
                'global_batch': world * B, 'frames_per_step_per_gpu': B * CROP,
                'workload': 'configs[%d]: train.py step, batch %d x [2,1025,256] per GPU, fwd + L1 + bwd%s + Adam; '
                            'Dropout2d live (library RNG)' % (4 if bf16 else 3, B, ' + RCCL all-reduce (%s bucket)' % wire if world > 1 else ''),
                'dtype': 'bf16 MFMA operands (Winograd forward / data-gradient / weight-gradient convs, 1x1 weight-gradient GEMM), '
-                        'fp32 accumulation, storage, master weights and Adam; remaining convs fp32' if bf16 else 'f32',
+                        'fp32 accumulation, storage, master weights and Adam; remaining convs fp32' if bf16 else SPLIT_DTYPE,
                'parallelism': 'dp%d (one RCCL all-reduce of the flat 14.74 M-element gradient bucket per step)' % world}
         return res, step
 
@@ -280,17 +340,18 @@ def main():
             if args.seconds == 30.0 else '%.0f s synthetic song, %d crops' % (args.seconds, res['crops_per_step_per_gpu'])
         metric = 'spectrogram-frames/sec (inference, CascadedNet n_fft=2048)'
         parallelism = 'replicas x%d (songs shard, no collective)' % world
-        roof = roofline(step, CONV_FAMILY_INFER, 'r02_infer_pmc.json' if primary_mode == 'infer' else 'r02_tta_pmc.json')
+        roof = roofline(step, CONV_FAMILY_INFER, 'r03_infer_pmc.json' if primary_mode == 'infer' else 'r03_tta_pmc.json')
     else:
         res, step = run_train(args.bf16)
         workload, metric, parallelism = res['workload'], 'spectrogram-frames/sec (train-step, CascadedNet n_fft=2048)', res['parallelism']
-        roof = roofline(step, CONV_FAMILY_TRAIN, 'r02_train_pmc.json')
+        roof = roofline(step, CONV_FAMILY_TRAIN, 'r03_train_pmc.json')
         net.eval()
     if rank == 0:
         out = {
             'metric': metric, 'value': res['frames_per_sec'], 'unit': 'spectrogram-frames/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': res['ms_per_step'],
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': res.get('dtype', 'f32'),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': res.get('dtype', SPLIT_DTYPE),
+            'ms_per_step_per_rank': res.get('ms_per_step_per_rank'), 'allreduce_ms': res.get('allreduce_ms'),
             'data': 'synthetic (seeded noise + sines; seeded random weights, no baseline.pth exists)',
             'config': {'workload': workload, 'n_fft': N_FFT, 'hop': HOP, 'cropsize': CROP,
                        'frames_per_step_per_gpu': res['frames_per_step_per_gpu'], 'parallelism': parallelism,
@@ -308,16 +369,17 @@ def main():
             dt = timed(lambda: sp.separate_wave(wave_host, tta=False), max(3, args.steps // 2), 1)
             extra['pcie_inclusive_frames_per_sec'] = T * max(3, args.steps // 2) / dt
         tta_res, tta_step = run_infer(True)
-        tta_roof = roofline(tta_step, CONV_FAMILY_INFER, 'r02_tta_pmc.json')
+        tta_roof = roofline(tta_step, CONV_FAMILY_INFER, 'r03_tta_pmc.json')
         train_res, train_step_fn = run_train()
-        train_roof = roofline(train_step_fn, CONV_FAMILY_TRAIN, 'r02_train_pmc.json')
+        train_roof = roofline(train_step_fn, CONV_FAMILY_TRAIN, 'r03_train_pmc.json')
         bf_res, _ = run_train(True)
         net.set_option('mfma_bf16', 0)
-        # the exact-fp32-by-split-bf16 multiply mode of the 64-cout Winograd kernel, beside the v_mfma_f32_32x32x2_f32 numbers above
-        net.set_option('mfma_mode', 2)
-        sp_inf, _ = run_infer(False)
-        net.set_option('mfma_mode', 2)          # (run_train resets the mode through 'mfma_bf16')
-        sp_trn = None
+        # the same workloads with v_mfma_f32_32x32x2_f32 everywhere (mfma_mode 0: Winograd F(2x2,3x3) on the fp32 matrix pipe for the
+        # 3x3 stride-1 layers, materialised decoder upsample) -- the round-1/2 arithmetic, beside the default above
+        net.set_option('mfma_mode', 0)
+        f32_inf, _ = run_infer(False)
+        net.set_option('mfma_mode', 0)          # (run_train returns to the default mode through 'mfma_bf16')
+        f32_trn = None
         try:
             from vocal_remover_amd import train as vtrain
             trainer = vtrain.Trainer(net, lr=1e-3, world_size=world, rank=rank, backend='rccl' if world > 1 else 'none',
@@ -328,9 +390,9 @@ def main():
             ys = (Xs * torch.rand((B, 2, N_FFT // 2 + 1, CROP), generator=g)).to(dev)
             Xs = Xs.to(dev)
             dts = timed(lambda: trainer.step(Xs, ys), args.steps, args.warmup)
-            sp_trn = {'frames_per_sec': world * B * CROP * args.steps / dts, 'ms_per_step': dts / args.steps * 1e3}
+            f32_trn = {'frames_per_sec': world * B * CROP * args.steps / dts, 'ms_per_step': dts / args.steps * 1e3}
         finally:
-            net.set_option('mfma_mode', 0)
+            net.set_option('mfma_mode', -1)
         net.eval()
         if rank == 0:
             out['config']['pcie_inclusive_frames_per_sec'] = extra.get('pcie_inclusive_frames_per_sec')
@@ -341,27 +403,30 @@ def main():
             out['train'] = {'metric': 'spectrogram-frames/sec (train-step, configs[3])', 'value': train_res['frames_per_sec'],
                             'ms_per_step': train_res['ms_per_step'], 'steps': args.steps, 'warmup': args.warmup,
                             'global_batch': train_res['global_batch'], 'workload': train_res['workload'],
-                            'parallelism': train_res['parallelism'], 'dtype': 'f32', 'roofline': train_roof}
-            out['train_bf16'] = {'metric': 'spectrogram-frames/sec (train-step, configs[4] arithmetic on %d GPU%s)' % (world, 's' if world > 1 else ''),
+                            'parallelism': train_res['parallelism'], 'dtype': SPLIT_DTYPE, 'roofline': train_roof,
+                            'ms_per_step_per_rank': train_res['ms_per_step_per_rank'], 'allreduce_ms': train_res['allreduce_ms']}
+            out['train_bf16'] = {'metric': 'spectrogram-frames/sec (train-step with bf16 MFMA OPERANDS on fp32 storage, %d GPU%s -- NOT configs[4] '
+                                           'itself: no bf16 activation storage%s)' % (world, 's' if world > 1 else '', '' if world > 1 else ', no data parallelism'),
                                  'value': bf_res['frames_per_sec'], 'ms_per_step': bf_res['ms_per_step'], 'steps': args.steps,
                                  'warmup': args.warmup, 'global_batch': bf_res['global_batch'], 'workload': bf_res['workload'],
                                  'parallelism': bf_res['parallelism'], 'dtype': bf_res['dtype']}
-            out['split_bf16'] = {
-                'what': "vr_set_option('mfma_mode', 2): the 64-cout Winograd forward / data-gradient kernel forms every fp32 product as six "
-                        'bf16 products of three-way split operands on v_mfma_f32_32x32x16_bf16, fp32 accumulation; error vs fp64 equal to '
-                        'the fp32-MFMA kernel (tests/test_gpu_parity.py::test_conv_winograd_split_bf16_mode_is_fp32_exact); default is mode 0',
-                'dtype': 'f32 (bf16x3 split, 6 products, fp32 accumulate)',
-                'infer': {'value': sp_inf['frames_per_sec'], 'ms_per_step': sp_inf['ms_per_step']},
-                'train': {'value': sp_trn['frames_per_sec'], 'ms_per_step': sp_trn['ms_per_step']} if sp_trn else None}
+            out['fp32_mfma'] = {
+                'what': "vr_set_option('mfma_mode', 0): every convolution on v_mfma_f32_32x32x2_f32 / 16x16x4 (fp32 operands; Winograd "
+                        'F(2x2,3x3) for the 3x3 stride-1 layers, decoder upsample materialised) -- the default (mode 2) instead forms the '
+                        'fp32 products of those layers from six bf16 products on v_mfma_f32_32x32x16_bf16; both modes pass the same parity '
+                        'tests at the same tolerances (tests/test_gpu_parity.py, test_gpu_configs.py, test_gpu_b16.py)',
+                'dtype': 'f32',
+                'infer': {'value': f32_inf['frames_per_sec'], 'ms_per_step': f32_inf['ms_per_step']},
+                'train': {'value': f32_trn['frames_per_sec'], 'ms_per_step': f32_trn['ms_per_step']} if f32_trn else None}
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             if primary_mode in ('infer', 'tta'):
                 out['cpu_baseline'] = cpu_baseline_infer(sd)
             else:
-                out['cpu_baseline'] = cpu_baseline_train(sd)
+                out['cpu_baseline'] = cpu_baseline_train(sd, args.train_batch)
             if args.mode == 'all':
-                out['train']['cpu_baseline'] = cpu_baseline_train(sd)
+                out['train']['cpu_baseline'] = cpu_baseline_train(sd, args.train_batch)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

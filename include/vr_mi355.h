@@ -64,14 +64,17 @@ int vr_set_mode(vr_handle h, int training);
  * "adam_reset": zero the Adam moments and the step counter (what constructing a new
  * torch.optim.Adam does; train.py:215-218).  "serial_exec" (default 0): 1 = every kernel on the handle's one
  * stream, no lanes / side streams (tests: results must not depend on the concurrent executor).
- * "mfma_bf16" (default 0; configs[4]): 1 = the Winograd convolutions (forward, data gradient, weight gradient) and
- * the 1x1 weight-gradient GEMM round their MFMA operands to bf16 (RNE, in registers) and run on
- * v_mfma_f32_32x32x8_bf16; accumulation, every stored tensor, the master weights and Adam stay fp32.
- * "mfma_mode" (default 0): how the Winograd kernels multiply.  0 = v_mfma_f32_32x32x2_f32 (fp32 operands);
- * 1 = the same as "mfma_bf16" 1;  2 = fp32 products assembled from six bf16 products of three-way split operands
- * (x = x1 + x2 + x3 exactly, a*b = a1b1 + a2b1 + a1b2 + a2b2 + a1b3 + a3b1, fp32 accumulation) on
- * v_mfma_f32_32x32x16_bf16 in the 64-cout forward / data-gradient kernel: error equal to mode 0's against fp64,
- * about 3 % faster end to end.  Everything else (storage, the other kernels, the weight gradients) is unchanged.
+ * "mfma_mode" (default 2): how the 3x3 stride-1 convolutions (84 % of the multiply-adds) form their products.
+ *   2 = fp32 products assembled from six bf16 products of three-way split operands (x = x1 + x2 + x3 exactly,
+ *       a*b = a1b1 + a2b1 + a1b2 + a2b2 + a1b3 + a3b1, fp32 accumulation) on v_mfma_f32_32x32x16_bf16 -- the direct kernel
+ *       conv_x3.hip, forward and data gradient; error against fp64 = an fp32 direct convolution's (tests); in eval the
+ *       decoder's bilinear x2 is fused into the full-resolution layers.  Storage, the other kernels and the weight gradients
+ *       are unchanged (fp32).
+ *   0 = v_mfma_f32_32x32x2_f32 (fp32 operands) throughout: Winograd F(2x2,3x3) / direct kernels (the round-1/2 default).
+ *   1 = bf16 MFMA operands (configs[4] arithmetic): the Winograd convolutions (forward, data gradient, weight gradient) and
+ *       the 1x1 weight-gradient GEMM round their operands to bf16 (RNE, in registers); accumulation, every stored tensor, the
+ *       master weights and Adam stay fp32.   -1 = back to the handle's default (2, or VR_MFMA_MODE).
+ * "mfma_bf16": 1 = "mfma_mode" 1; 0 = back to the handle's default mode.
  * "params_dirty": the parameter arena was written from outside (vr_param_arena).                              */
 int vr_set_option(vr_handle h, const char* name, int value);
 

@@ -157,7 +157,7 @@ def test_full_net_train_step(vr, full):
             state = model.state_dict()
         finally:
             model.set_dropout_masks(None)
-            model.set_option('mfma_mode', 0)
+            model.set_option('mfma_mode', -1)
             model.load_state_dict(sd)
             model.eval()
         _check_full_net_train_step(mode, loss, mask, grads, state, loss64, g64, g32, sd64, want_mask, e32)

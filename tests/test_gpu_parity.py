@@ -188,7 +188,7 @@ def test_conv_winograd_split_bf16_mode_is_fp32_exact(vr, small, case):
                                                 flags, None, ctypes.c_float(1.0), None, nat.np_ptr(out), None))
             got[key] = out
     finally:
-        model.set_option('mfma_mode', 0)
+        model.set_option('mfma_mode', -1)
 
     def err(a):
         e = np.abs(a - want)
@@ -323,7 +323,7 @@ def test_predict_mask_full_net_split_bf16_mode(full):
         model.set_option('mfma_mode', 2)
         got = model.predict_mask(x.to('cuda:0')).cpu()
     finally:
-        model.set_option('mfma_mode', 0)
+        model.set_option('mfma_mode', -1)
     diff = (got - want).abs()
     print('full net, split mode: max-abs %.3e mean-abs %.3e; vs mode 0: %.3e' % (float(diff.max()), float(diff.mean()), float((got - ref).abs().max())))
     assert float(diff.max()) < 1e-4 and float(diff.mean()) < 1e-5

@@ -14,11 +14,11 @@ print('infer', j['value'], j['ms_per_step'], j['roofline']['frac'], 'pcie', j['c
 print('tta', j['tta']['value'], j['tta']['ms_per_step'], j['tta']['roofline']['frac'])
 print('train', j['train']['value'], j['train']['ms_per_step'], j['train']['roofline']['frac'])
 print('train_bf16', j['train_bf16']['value'], j['train_bf16']['ms_per_step'])
-print('split_bf16', j['split_bf16']['infer'], j['split_bf16']['train'])
+print('fp32_mfma', j['fp32_mfma']['infer'], j['fp32_mfma']['train'])
 print('cpu', j['cpu_baseline']['value'], j['train']['cpu_baseline']['value'])
 PY
 export VR_NO_SIDE_STREAM=1 VR_NO_SPLIT_BATCH=1
-for m in train infer; do
+for m in train infer tta; do
   timeout 400 rocprofv3 --kernel-trace --stats -d $O/kt_$m -o r -- python bench.py --mode $m --steps 2 --warmup 1 --no-cpu-baseline > $O/kt_$m.log 2>&1
   python tools/rocpd_summary.py $(ls $O/kt_$m/*.db | head -1) $O/${m}_kernel_trace.md > /dev/null
   timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_f_$m -o r -- python bench.py --mode $m --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc_f_$m.log 2>&1
@@ -34,8 +34,8 @@ for m in infer train; do
   python tools/pmc_sq_summary.py $(ls $O/sq_$m/*.db | head -1) $(ls $O/sq_cal/*.db | head -1) $O/${m}_sq_pmc.json > $O/${m}_sq_pmc.md
 done
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-# the whole GPU suite once more with the split-bf16 multiply mode as the default of every handle (same tolerances)
-VR_MFMA_MODE=2 timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/pytest_mfma_mode2.log 2>&1; echo "pytest (VR_MFMA_MODE=2) rc=$?"; tail -1 $O/pytest_mfma_mode2.log
+# the whole GPU suite once more with the fp32-MFMA mode as the default of every handle (same tolerances)
+VR_MFMA_MODE=0 timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/pytest_mfma_mode0.log 2>&1; echo "pytest (VR_MFMA_MODE=0) rc=$?"; tail -1 $O/pytest_mfma_mode0.log
 find $O -name "*.db" -delete
 head -12 $O/train_kernel_trace.md; tail -1 $O/train_kernel_trace.md; head -3 $O/train_pmc.md; head -3 $O/infer_pmc.md
 head -8 $O/train_sq_pmc.md | cut -c1-120; grep "all kernels" $O/*_sq_pmc.md

@@ -150,10 +150,14 @@ public:
                      int B, int T, int bins, bool in_on_dev, float* Xmag, float* ymag, bool out_on_dev);
     char* aug_buf = nullptr; size_t aug_cap = 0;         // staging of the training input pipeline
     bool train_wino = true;                              // vr_set_option("train_winograd"): Winograd kernels in train mode
-    // vr_set_option("mfma_mode"): how the Winograd kernels multiply.  0 = v_mfma_f32_32x32x2_f32 (exact fp32 products);
-    // 1 = operands rounded to bf16 (configs[4]; "mfma_bf16" 1 is the same); 2 = fp32 products as six bf16 products of
-    // three-way split operands, fp32 accumulation (conv_stage.h) -- forward and data-gradient convs, weight gradients stay on 0.
-    int mfma_mode = 0;
+    // vr_set_option("mfma_mode"): how the 3x3 stride-1 convs multiply.
+    //   2 (default) = fp32 products as six bf16 products of three-way split operands on v_mfma_f32_32x32x16_bf16, fp32 accumulation
+    //       (conv_x3.hip: direct conv, error vs fp64 = an fp32 direct convolution's; forward and data-gradient convs -- weight
+    //       gradients stay on the fp32 MFMA);
+    //   0 = v_mfma_f32_32x32x2_f32 throughout (Winograd F(2x2,3x3) / direct kernels, round-1/2 default);
+    //   1 = operands rounded to bf16 (configs[4] arithmetic; "mfma_bf16" 1 is the same).
+    int mfma_mode = 2;
+    int default_mfma_mode = 2;                           // (VR_MFMA_MODE overrides; "mfma_mode" -1 / "mfma_bf16" 0 return to it)
     bool serial = false;                                 // vr_set_option("serial_exec"): no lanes / side streams (tests: race detector)
     void set_option(const std::string& name, int value);
     void reset_adam_state();

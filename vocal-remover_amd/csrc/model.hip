@@ -127,6 +127,7 @@ Model::Model(int device_, int n_fft_, int hop_, int nout_, int nout_lstm_)
     VR_CHECK((max_bin / 2) % 16 == 0, -2, "n_fft/4 must be a multiple of 16 (four stride-2 encoders)");
     DeviceGuard dev_guard(device);
     if (const char* e = getenv("VR_MFMA_MODE")) { mfma_mode = atoi(e); VR_CHECK(mfma_mode >= 0 && mfma_mode <= 2, -2, "VR_MFMA_MODE: 0, 1 or 2"); }
+    default_mfma_mode = mfma_mode;
     VR_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     if (!getenv("VR_NO_SIDE_STREAM")) {
         VR_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
@@ -337,10 +338,10 @@ void Model::set_option(const std::string& name, int value) {
     if (name == "train_winograd") train_wino = value != 0;
     else if (name == "serial_exec") serial = value != 0;     // every kernel on the handle's one stream (race detector of the tests)
     else if (name == "params_dirty") affine_dirty = true;    // the parameter arena was written from outside (vr_param_arena)
-    else if (name == "mfma_bf16") { mfma_mode = value != 0 ? 1 : 0; affine_dirty = true; }   // bf16 operands on the matrix pipe, fp32 storage / accumulation
-    else if (name == "mfma_mode") {                          // 0 exact fp32 MFMA, 1 bf16 operands, 2 fp32 via 6 bf16 products (model.h)
-        if (value < 0 || value > 2) throw Error(-2, "mfma_mode: 0, 1 or 2");
-        mfma_mode = value; affine_dirty = true;              // (the next eval forward refreshes the Winograd weight copies)
+    else if (name == "mfma_bf16") { mfma_mode = value != 0 ? 1 : default_mfma_mode; affine_dirty = true; }   // bf16 operands on the matrix pipe (0: back to the handle's default mode)
+    else if (name == "mfma_mode") {                          // 0 fp32 MFMA, 1 bf16 operands, 2 fp32 via 6 bf16 products (model.h); -1 = the default
+        if (value < -1 || value > 2) throw Error(-2, "mfma_mode: 0, 1, 2 or -1 (default)");
+        mfma_mode = value < 0 ? default_mfma_mode : value; affine_dirty = true;   // (the next eval forward refreshes the derived weight copies)
     }
     else if (name == "adam_reset") reset_adam_state();      // a freshly constructed torch.optim.Adam has no moments
     else throw Error(-2, "unknown option: " + name);
