@@ -174,7 +174,7 @@ void wgrad_gemm_plan(WgradArgs& a) {
 void wgrad_gemm_launch(const WgradArgs& a, hipStream_t st) {
     static std::atomic<unsigned long long> attr_done{0}, attr_done_bf{0};          // per device (bit = device index)
     const int grid = ((a.P + 7) / 8) * 8 * a.nchunks * a.nct;
-    if (a.bf16) {
+    if (a.bf16 == 1) {
         ensure_lds_attr(attr_done_bf, reinterpret_cast<const void*>(wgrad_gemm_kernel<true>), WgGemmCfg::LDS_BYTES);
         hipLaunchKernelGGL(wgrad_gemm_kernel<true>, dim3(grid), dim3(512), WgGemmCfg::LDS_BYTES, st, a, a.tiles_w,
                            (long long)a.in.Hout * a.in.Wout);

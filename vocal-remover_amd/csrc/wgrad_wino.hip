@@ -378,7 +378,7 @@ void wgrad_wino_launch(const WgradArgs& a_in, int CB, int MT, hipStream_t st) {
     WgradArgs a = a_in;
     static const int dbg = [] { const char* e = getenv("VR_WW_DBG"); return e ? atoi(e) : 0; }();   // ablations (perf only)
     a.in.dbg = dbg;
-    if (a.bf16) {
+    if (a.bf16 == 1) {
         if (CB == 32 && MT == 64) ww_launch<32, 64, true>(a, st);
         else if (CB == 64 && MT == 32) ww_launch<64, 32, true>(a, st);
         else ww_launch<32, 32, true>(a, st);
