@@ -93,6 +93,35 @@ def test_reference_train_epoch_statements_run_through_the_autograd_shim(vr):
     assert any(float(v.abs().max()) > 0 for v in b.grads(keys={'stg3_full_band_net.dec1.conv1.conv.0.weight'}).values())
 
 
+def test_flat_parameter_is_detached_when_the_handle_goes_away(vr):
+    """the flat Parameter / .grad are zero-copy views of the native arenas.  Moving the model off the GPU (or to another
+    one) closes the handle: optimizers built before must neither touch freed memory nor silently stop updating the new handle."""
+    from vocal_remover_amd import train as vtrain
+    m, sd = _model(vr)
+    m.train(); m.set_dropout_masks(None)
+    old = m.parameters()[0]
+    torch_opt = torch.optim.Adam([old], lr=1e-3)
+    native_opt = vtrain.Adam(m.parameters(), lr=1e-3)
+    X, y = train_step.synth_batch(2, T=64, n_fft=N_FFT, seed=3)
+    m.train_step(X.to(DEV), y.to(DEV), 1)
+    assert old.numel() > 1000 and old.grad is not None and float(old.grad.abs().max()) > 0
+    m.to('cpu')
+    assert old.numel() == 0 and old.grad is None          # detached: nothing left that points into the freed arenas
+    torch_opt.step()                                       # a stale torch optimizer steps an empty tensor: harmless
+    m.to(torch.device(DEV))
+    new = m.parameters()[0]
+    assert new is not old and new.numel() > 1000 and new.data_ptr() != 0
+    with pytest.raises(RuntimeError):
+        native_opt.step()                                  # its moments lived in the closed handle
+    # the new handle trains with a fresh optimizer
+    m.train(); m.set_dropout_masks(None)
+    opt = vtrain.Adam(m.parameters(), lr=1e-3)
+    before = m.state_dict()['out.weight'].clone()
+    m.train_step(X.to(DEV), y.to(DEV), 1)
+    opt.step()
+    assert not torch.equal(m.state_dict()['out.weight'], before)
+
+
 def test_resample_kaiser_fast_vs_restatement_and_properties(vr):
     rng = np.random.default_rng(0)
     x = rng.standard_normal((2, 3000)).astype(np.float32)

@@ -159,6 +159,55 @@ def test_conv_winograd_vs_torch(vr, small, case):
     assert abs(rel - direct) < 1e-4
 
 
+UP_CASES = [
+    # N, Cin, H (low-res), W (low-res), Cout, epi, slope, bias      conv input = bilinear x2 of the source (lib/layers.py:52)
+    (2, 16, 20, 32, 32, 1, 0.0, 0),
+    (1, 40, 9, 24, 64, 1, 0.01, 1),          # odd low-res H, 48 output columns (partial 32-column tile), bias + epilogue
+    (2, 8, 64, 64, 16, 0, 1.0, 0),           # 16 couts (padded to one 32-cout tile), 128 x 128 outputs
+    (1, 97, 16, 16, 32, 1, 0.0, 0),          # dec1-like channel count, 32 x 32 outputs
+    (3, 24, 5, 16, 40, 0, 1.0, 1),           # 10 x 32 outputs: one partial row tile per image
+]
+
+
+@pytest.mark.parametrize('case', UP_CASES, ids=str)
+def test_conv_x3_fused_upsample_vs_torch(vr, small, case):
+    """The decoder's F.interpolate(x2, bilinear, align_corners=True) fused into the split-bf16 direct kernel (conv_x3.hip: low-
+    resolution tile in LDS, interpolation inside the split pass) against torch's upsample + conv2d, and against the library's own
+    fp32 fused-loader kernel (mfma_mode 0) -- same bar as every other conv: 1e-4 of the output scale."""
+    N, Cin, H, W, Cout, use_epi, slope, use_bias = case
+    model = small[0]
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    epi = torch.stack([torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.3], 1) if use_epi else None
+    bias = torch.randn(Cout, generator=g) if use_bias else None
+    want = F.conv2d(F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True), w, bias, 1, 1)
+    if epi is not None:
+        want = want * epi[:, 0].view(1, -1, 1, 1) + epi[:, 1].view(1, -1, 1, 1)
+        want = torch.where(want > 0, want, want * slope)
+    nat = vr.native
+    xn, wn = x.numpy(), w.numpy()
+    en = epi.numpy().copy() if epi is not None else None
+    bn = bias.numpy() if bias is not None else None
+    got = {}
+    try:
+        for mode in (2, 0):
+            model.set_option('mfma_mode', mode)
+            out = np.empty(tuple(want.shape), np.float32)
+            nat.check(nat.lib().vr_debug_conv2d(
+                model._handle.h, nat.np_ptr(xn), N, Cin, H, W, nat.np_ptr(wn), Cout, 3, 1, 1, 1, 1 | 2 | (4 if use_epi else 0),
+                nat.np_ptr(en) if en is not None else None, ctypes.c_float(slope if use_epi else 1.0),
+                nat.np_ptr(bn) if bn is not None else None, nat.np_ptr(out), None))
+            got[mode] = out
+    finally:
+        model.set_option('mfma_mode', -1)
+    scale = float(want.abs().max())
+    e2, e0 = float(np.abs(got[2] - want.numpy()).max()) / scale, float(np.abs(got[0] - want.numpy()).max()) / scale
+    print('fused upsample: split-bf16 direct %.2e, fp32 fused loader %.2e of the output scale' % (e2, e0))
+    assert e2 < 1e-4 and e0 < 1e-4
+    assert not np.array_equal(got[0], got[2])
+
+
 SPLIT_CASES = [(3, 64, 128, 256, 64), (3, 61, 128, 256, 64), (3, 128, 64, 256, 128)]      # big enough for the 64-cout Winograd variant
 
 
