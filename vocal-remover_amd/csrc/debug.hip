@@ -92,7 +92,8 @@ void Model::debug_kernel(const std::string& name, const int64_t* dims, int ndims
         DevBuf h((size_t)N * 2 * H * T), save((size_t)N * 2 * T * 5 * H), dgx((size_t)N * 2 * G * T), dwf((size_t)G * H), dwr((size_t)G * H);
         launch_bilstm_train(gx.p, wf.p, wr.p, h.p, save.p, N, T, H, st);
         launch_bilstm_bwd(dh.p, save.p, wf.p, wr.p, dgx.p, N, T, H, st);
-        launch_lstm_whh_grad(dgx.p, h.p, dwf.p, dwr.p, N, T, H, 1, st);
+        DevBuf wpart(lstm_whh_grad_scratch_floats(N, H));
+        launch_lstm_whh_grad(dgx.p, h.p, dwf.p, dwr.p, N, T, H, 1, wpart.p, st);
         VR_HIP(hipStreamSynchronize(st));
         h.download(out[0]); dgx.download(out[1]); dwf.download(out[2]); dwr.download(out[3]);
     } else if (name == "upsample") {

@@ -84,8 +84,9 @@ void launch_bilstm_train(const float* gx, const float* whh_f, const float* whh_r
 void launch_bilstm_bwd(const float* dh, const float* save, const float* whh_f, const float* whh_r, float* dgx,
                        int N, int T, int H, hipStream_t st);
 // dW_hh[dir][g][k] = sum_{n,t} dgx[n][dir*4H+g][t] * h_prev[n][dir*H+k][t]
+size_t lstm_whh_grad_scratch_floats(int N, int H);      // floats of `part` below (one slab per sample slice and direction)
 void launch_lstm_whh_grad(const float* dgx, const float* hout, float* dwhh_f, float* dwhh_r, int N, int T, int H,
-                          int accumulate, hipStream_t st);
+                          int accumulate, float* part, hipStream_t st);
 
 // ---- backward.hip -------------------------------------------------------------------------------
 struct BnBwdArgs {

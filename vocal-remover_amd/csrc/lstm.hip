@@ -292,52 +292,105 @@ void launch_bilstm_bwd(const float* dh, const float* save, const float* whh_f, c
 }
 
 // dW_hh[g][k] = sum_{n,t} dgx[n][g][t] * h[n][k][t -/+ 1]   (forward / reverse direction): a small GEMM over (n,t).
-// Workgroup = 16 gate rows x 64 hidden columns; per (sample, 64-frame block) the dgx rows and the shifted h rows
-// are staged in LDS with coalesced reads, thread (k, 4 gate rows) accumulates 64 frames from LDS.
+// Workgroup = 16 gate rows x 64 hidden columns x one slice of the samples (blockIdx.y = slice * 2 + direction); per (sample,
+// 64-frame block) the dgx rows and the shifted h rows are staged in LDS with coalesced reads -- the loads of the next block are in
+// flight (registers) while thread (k, 4 gate rows) accumulates the 64 frames of this one.  Each slice writes its own partial slab
+// and lstm_whh_reduce_kernel adds the slabs in a fixed order: deterministic, no atomics.
+//
+// The operand reads of a step are waited for with an explicit lgkmcnt(0) before the first FMA.  The compiler's own schedule
+// (counted lgkmcnt waits, v_pk_fma_f32 straight behind them) is NOT safe on gfx950 beside conv_x3's TH = 8 kernels: with one of
+// those resident on the same CU the last 16 lanes of the first dword of a broadcast ds_read_b128 were consumed before they had
+// landed (tools/vgpr_canary.hip reproduces it in isolation: every run wrong in rows g%4 in {0,2}, columns 48..63; 0 wrong with
+// the full wait) -- the "race" the batch-16 three-stream test caught in round 3 (hardware fact 5).
+constexpr int WHH_MAX_SLICES = 8;
+
 __global__ __launch_bounds__(256) void lstm_whh_grad_kernel(const float* __restrict__ dgx, const float* __restrict__ hout,
-                                                            float* dwf, float* dwr, int N, int T, int H, int accumulate) {
+                                                            float* __restrict__ part, int N, int T, int H, int nslice) {
     __shared__ float hs[64][65];
     __shared__ float dgs[16][64];
-    const int g0 = blockIdx.x * 16, dir = blockIdx.y, k0 = blockIdx.z * 64;
+    const int g0 = blockIdx.x * 16, dir = blockIdx.y & 1, slice = blockIdx.y >> 1, k0 = blockIdx.z * 64;
     const int G = 4 * H;
     const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;      // wq: which 4 of the 16 gate rows / staging row phase
-    float* dw = dir ? dwr : dwf;
     const int sh = dir ? 1 : -1;
+    const int n_lo = (int)((long long)N * slice / nslice), n_hi = (int)((long long)N * (slice + 1) / nslice);
+    const int tblocks = (T + 63) / 64, ntile = (n_hi - n_lo) * tblocks;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int n = 0; n < N; ++n) {
-        for (int t0 = 0; t0 < T; t0 += 64) {
-            const int t = t0 + lane, th = t + sh;
-            const bool ok = t < T && th >= 0 && th < T;
-            for (int r = wq; r < 64; r += 4) {
-                const int k = k0 + r;
-                hs[r][lane] = (ok && k < H) ? hout[((long long)n * 2 * H + (long long)dir * H + k) * T + th] : 0.f;
-            }
-            for (int r = wq; r < 16; r += 4) {
-                const int g = g0 + r;
-                dgs[r][lane] = (ok && g < G) ? dgx[((long long)n * 2 * G + (long long)dir * G + g) * T + t] : 0.f;
-            }
-            __syncthreads();
-#pragma unroll 8
-            for (int tt = 0; tt < 64; ++tt) {
-                const float hv = hs[lane][tt];
+    float ph[16], pd[4];
+    auto fetch = [&](int tile) {
+        const int n = n_lo + tile / tblocks, t = (tile % tblocks) * 64 + lane, th = t + sh;
+        const bool ok = tile < ntile && t < T && th >= 0 && th < T;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = fmaf(dgs[wq * 4 + q][tt], hv, acc[q]);
-            }
-            __syncthreads();
+        for (int j = 0; j < 16; ++j) {
+            const int k = k0 + wq + 4 * j;
+            ph[j] = (ok && k < H) ? hout[((long long)n * 2 * H + (long long)dir * H + k) * T + th] : 0.f;
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int g = g0 + wq + 4 * j;
+            pd[j] = (ok && g < G) ? dgx[((long long)n * 2 * G + (long long)dir * G + g) * T + t] : 0.f;
+        }
+    };
+    fetch(0);
+    for (int tile = 0; tile < ntile; ++tile) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) hs[wq + 4 * j][lane] = ph[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dgs[wq + 4 * j][lane] = pd[j];
+        __syncthreads();
+        fetch(tile + 1);
+#pragma unroll 1
+        for (int tb = 0; tb < 64; tb += 8) {
+            float hv[8], dg[4][8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hv[j] = hs[lane][tb + j];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dg[q][j] = dgs[wq * 4 + q][tb + j];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(hv[j]));
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(dg[q][j]));
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = fmaf(dg[q][j], hv[j], acc[q]);
+        }
+        __syncthreads();
     }
     const int k = k0 + lane;
+    float* slab = part + (size_t)(slice * 2 + dir) * G * H;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int g = g0 + wq * 4 + q;
-        if (g < G && k < H) dw[g * H + k] = accumulate ? dw[g * H + k] + acc[q] : acc[q];
+        if (g < G && k < H) slab[g * H + k] = acc[q];
     }
 }
 
+__global__ __launch_bounds__(256) void lstm_whh_reduce_kernel(const float* __restrict__ part, float* dwf, float* dwr, int GH, int nslice,
+                                                              int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x, dir = blockIdx.y;
+    if (i >= GH) return;
+    float s = 0.f;
+    for (int sl = 0; sl < nslice; ++sl) s += part[(size_t)(sl * 2 + dir) * GH + i];
+    float* dw = dir ? dwr : dwf;
+    dw[i] = accumulate ? dw[i] + s : s;
+}
+
+static int whh_slices(int N) { return N < WHH_MAX_SLICES ? (N < 1 ? 1 : N) : WHH_MAX_SLICES; }
+
+size_t lstm_whh_grad_scratch_floats(int N, int H) { return (size_t)whh_slices(N) * 2 * 4 * H * H; }
+
 void launch_lstm_whh_grad(const float* dgx, const float* hout, float* dwhh_f, float* dwhh_r, int N, int T, int H,
-                          int accumulate, hipStream_t st) {
-    hipLaunchKernelGGL(lstm_whh_grad_kernel, dim3((4 * H + 15) / 16, 2, (H + 63) / 64), dim3(256), 0, st, dgx, hout, dwhh_f,
-                       dwhh_r, N, T, H, accumulate);
+                          int accumulate, float* part, hipStream_t st) {
+    const int ns = whh_slices(N), GH = 4 * H * H;
+    hipLaunchKernelGGL(lstm_whh_grad_kernel, dim3((4 * H + 15) / 16, 2 * ns, (H + 63) / 64), dim3(256), 0, st, dgx, hout, part, N, T,
+                       H, ns);
+    VR_HIP(hipGetLastError());
+    hipLaunchKernelGGL(lstm_whh_reduce_kernel, dim3((GH + 255) / 256, 2), dim3(256), 0, st, part, dwhh_f, dwhh_r, GH, ns, accumulate);
     VR_HIP(hipGetLastError());
 }
 

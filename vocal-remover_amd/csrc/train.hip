@@ -362,9 +362,10 @@ void Model::backward() {
         case TK_LSTM: {
             LSTMMod& M = *r.M;
             const int H = M.hid, G = 4 * H, T = r.out.W, N = r.N;
+            float* wpart = ws.allocf(lstm_whh_grad_scratch_floats(N, H));
             if (!dry) {
                 launch_bilstm_bwd(r.out.g, r.save, M.whh_f->dev, M.whh_r->dev, r.aux.g, N, T, H, stream);
-                launch_lstm_whh_grad(r.aux.g, r.out.p, grad_of(M.whh_f), grad_of(M.whh_r), N, T, H, 1, stream);
+                launch_lstm_whh_grad(r.aux.g, r.out.p, grad_of(M.whh_f), grad_of(M.whh_r), N, T, H, 1, wpart, stream);
                 // b_ih and b_hh enter the gates as a sum: both receive the channel sums of dgx
                 float* tmp = ws.allocf((size_t)2 * G);
                 launch_channel_sum(r.aux.g, N, 2 * G, T, tmp, 0, stream);
