@@ -4,7 +4,7 @@ Kernel dispatch depends on the grid size (conv_wino.hip: 64-cout variant only fr
 8x16 / 16x16 pixel tiles by workgroup count; conv_x3.hip: tile choice by workgroup count), so batch 16 launches variants that the
 batch-2 full-net test never reaches, and the train executor runs three streams.  Here:
 
-  * full net, batch 16: the three-stream executor vs serial_exec=1 (every kernel on ONE stream) and vs itself three times --
+  * full net, batch 16: the three-stream executor vs serial_exec=1 (every kernel on ONE stream) and vs itself eight times --
     loss, mask and every gradient;
   * single convs (forward, data gradient, weight gradient) at batch-16 grids on both sides of each dispatch threshold,
     vs torch autograd, 2e-4 of the tensor's scale -- in the fp32-MFMA mode and in the split-bf16 mode;
@@ -67,7 +67,8 @@ def test_b16_train_step_three_streams_vs_one(vr, full16):
     model, sd, X, y, masks = full16
     for mode in (0, 2):
         loss_s, mask_s, g_s = _step(model, sd, X, y, masks, serial_exec=1, mfma_mode=mode)
-        runs = [_step(model, sd, X, y, masks, mfma_mode=mode) for _ in range(3)]
+        # (eight repetitions: the round-3 weight_hh nondeterminism -- DESIGN.md hardware fact 5 -- showed in one run of four to eight)
+        runs = [_step(model, sd, X, y, masks, mfma_mode=mode) for _ in range(8)]
         worst, bit_equal = 0.0, True
         for loss, mask, g in runs:
             assert abs(loss - loss_s) <= 1e-6 * abs(loss_s), (mode, loss, loss_s)
