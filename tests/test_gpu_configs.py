@@ -107,7 +107,7 @@ def test_s30_concurrent_executor_is_race_free(vr, full, s30, tta):
     model.set_option('serial_exec', 1)
     ys, vs = [t.cpu().numpy() for t in sp.separate_wave(wd, tta=tta)]
     model.set_option('serial_exec', 0)
-    runs = [[t.cpu().numpy() for t in sp.separate_wave(wd, tta=tta)] for _ in range(3)]
+    runs = [[t.cpu().numpy() for t in sp.separate_wave(wd, tta=tta)] for _ in range(12)]
     for y, v in runs:
         assert np.abs(y - ys).max() < 1e-5 and np.abs(v - vs).max() < 1e-5
         assert np.array_equal(y, runs[0][0]) and np.array_equal(v, runs[0][1])       # no launch-order dependence at all

@@ -18,6 +18,7 @@
 // LDS read that follows a DMA it knows about (cdna_hip_programming.md "Pipelining across barriers").
 #include <cstdlib>
 
+#include "conv_epilogue.h"
 #include "conv_stage.h"
 #include "lds_dma.h"
 
@@ -48,7 +49,11 @@ struct DmaCfg {
     static constexpr int NWPASS = (NWP + 255) / 256;          // per wave
     static constexpr int CPW = CK / 4;                        // input channels per wave
     static constexpr int NS = KK * (CK / 2);                  // MFMA k-steps per chunk
-    static constexpr int LDS_BYTES = 2 * BUF * 4;
+    // epilogue constants of the cout tile (conv_epilogue.h): behind the two buffers -- unless those 3*MT floats would cost a
+    // workgroup per CU (the 1x1 tilings with exactly 40 KB); then they are fetched at the end and parked over buffer 0
+    static constexpr bool E_TAIL = (160 * 1024) / (2 * BUF * 4) == (160 * 1024) / ((2 * BUF + 3 * MT) * 4);
+    static constexpr int E_OFF = E_TAIL ? 2 * BUF : 0;
+    static constexpr int LDS_BYTES = (2 * BUF + (E_TAIL ? 3 * MT : 0)) * 4;
     static_assert(WN >= 1 && WN * 4 == NG, "pixel groups must split over the 4 waves");
     static_assert(CK % 4 == 0 && BUF % 4 == 0 && XS % 4 == 0 && CSX % 4 == 0, "16-B LDS slabs");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
@@ -129,6 +134,13 @@ __global__ __launch_bounds__(256, (DmaOcc<MT, TH, TW>::value)) void conv_dma_ker
                 if (pp * 64 + lane < NWP) dma16(ws_b + pp * 1024, woff[i], wr);
             }
         }
+        // The source fields as opaque VALUES: hipcc may turn a select between the loads a.src[si].x into one load from a run-time
+        // address inside the kernel-argument struct -- and then keeps the whole struct in scratch (seen on a 1x1 tiling).
+        long long f0N = a.src[0].sN, f1N = a.src[1].sN, f2N = a.src[2].sN, f0C = a.src[0].sC, f1C = a.src[1].sC, f2C = a.src[2].sC;
+        long long f0H = a.src[0].sH, f1H = a.src[1].sH, f2H = a.src[2].sH;
+        unsigned long long f0p = (unsigned long long)a.src[0].p, f1p = (unsigned long long)a.src[1].p, f2p = (unsigned long long)a.src[2].p;
+        asm volatile("" : "+s"(f0N), "+s"(f1N), "+s"(f2N), "+s"(f0C), "+s"(f1C), "+s"(f2C));
+        asm volatile("" : "+s"(f0H), "+s"(f1H), "+s"(f2H), "+s"(f0p), "+s"(f1p), "+s"(f2p));
 #pragma unroll
         for (int cc = 0; cc < CPW; ++cc) {
             const int cl = wave + 4 * cc;
@@ -140,10 +152,10 @@ __global__ __launch_bounds__(256, (DmaOcc<MT, TH, TW>::value)) void conv_dma_ker
             }
             const int si = (ci >= a.c1) + (ci >= a.c2);
             const int clc = ci - (si == 0 ? 0 : (si == 1 ? a.c1 : a.c2));
-            const float* sp = si == 0 ? a.src[0].p : (si == 1 ? a.src[1].p : a.src[2].p);
-            const long long sN = si == 0 ? a.src[0].sN : (si == 1 ? a.src[1].sN : a.src[2].sN);
-            const long long sC = si == 0 ? a.src[0].sC : (si == 1 ? a.src[1].sC : a.src[2].sC);
-            const unsigned sH4 = (unsigned)(si == 0 ? a.src[0].sH : (si == 1 ? a.src[1].sH : a.src[2].sH)) * 4u;
+            const float* sp = reinterpret_cast<const float*>(si == 0 ? f0p : (si == 1 ? f1p : f2p));
+            const long long sN = si == 0 ? f0N : (si == 1 ? f1N : f2N);
+            const long long sC = si == 0 ? f0C : (si == 1 ? f1C : f2C);
+            const unsigned sH4 = (unsigned)(si == 0 ? f0H : (si == 1 ? f1H : f2H)) * 4u;
             const i32x4 xr = make_rsrc(sp + (long long)n * sN + (long long)clc * sC, 0x7FFFFFF0u);
             const unsigned cb = xs_b + (unsigned)(cl * CSX * 4);
 #pragma unroll
@@ -172,7 +184,14 @@ __global__ __launch_bounds__(256, (DmaOcc<MT, TH, TW>::value)) void conv_dma_ker
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    if (a.dbg != 1) issue_chunk(0);
+    if constexpr (Cfg::E_TAIL) {
+        float ecv[3];
+        epi_fetch<MT>(a.bias, a.epi, a.Cout, co0, tid, ecv);
+        if (a.dbg != 1) issue_chunk(0);
+        epi_park<MT>(smem + Cfg::E_OFF, tid, ecv);
+    } else {
+        if (a.dbg != 1) issue_chunk(0);
+    }
     dma_wait_and_barrier();
 
     // ---- full chunks: software-pipelined (the LDS operands of step s+1 are read before the MFMAs of step s)
@@ -260,74 +279,22 @@ __global__ __launch_bounds__(256, (DmaOcc<MT, TH, TW>::value)) void conv_dma_ker
         }
     }
 
-    // ---------------- epilogue: bias, (eval) BatchNorm+activation, up to three destination segments -----
-    if (a.d1 >= a.CoutPad) {
-        // one destination (every forward conv): pixel offsets once per thread, one row pointer per cout
-        long long offn[WN];
-        bool okn[WN];
+    // ---------------- epilogue (conv_epilogue.h): bias, (eval) BatchNorm+activation, up to three destination segments -----
+    {
+        int hon[WN], won[WN];
 #pragma unroll
         for (int ni = 0; ni < WN; ++ni) {
             const int pix = (wave * WN + ni) * 32 + l31;
-            const int ho = h0 + pix / TW, wo = w0 + pix % TW;
-            okn[ni] = ho < a.Hout && wo < a.Wout && a.dst[0].p != nullptr;
-            offn[ni] = (long long)ho * a.dst[0].sH + ((long long)wo << a.dst[0].wshift);
+            hon[ni] = h0 + pix / TW; won[ni] = w0 + pix % TW;
         }
-        float* dbase = a.dst[0].p + (long long)n * a.dst[0].sN;
-        const int dacc = a.dst[0].accumulate;
-#pragma unroll
-        for (int mi = 0; mi < WM; ++mi) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                const int cc = co < a.Cout ? co : a.Cout - 1;
-                const float b = a.bias ? a.bias[cc] : 0.f;
-                float esc = 1.f, esh = 0.f, eslope = 1.f;
-                if (a.epi) { esc = a.epi[2 * cc]; esh = a.epi[2 * cc + 1]; eslope = a.epi_slope; }
-                float* qrow = dbase + (long long)co * a.dst[0].sC;
-#pragma unroll
-                for (int ni = 0; ni < WN; ++ni) {
-                    const float v = acc[mi][ni][r] + b;
-                    acc[mi][ni][r] = v;
-                    if (co < a.Cout && okn[ni]) {
-                        float* q = qrow + offn[ni];
-                        const float y = act_apply(fmaf(v, esc, esh), eslope);
-                        *q = dacc ? *q + y : y;
-                    }
-                }
-            }
+        if constexpr (!Cfg::E_TAIL) {                          // (one extra memory round trip per tile, 40-KB tilings only)
+            float ecv[3];
+            epi_fetch<MT>(a.bias, a.epi, a.Cout, co0, tid, ecv);
+            __syncthreads();                                   // every wave is done with buffer 0
+            epi_park<MT>(smem, tid, ecv);
+            __syncthreads();
         }
-    } else {
-#pragma unroll
-    for (int mi = 0; mi < WM; ++mi) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-            const int cc = co < a.Cout ? co : a.Cout - 1;
-            const float b = a.bias ? a.bias[cc] : 0.f;
-            float esc = 1.f, esh = 0.f, eslope = 1.f;
-            if (a.epi) { esc = a.epi[2 * cc]; esh = a.epi[2 * cc + 1]; eslope = a.epi_slope; }
-            const int seg = (co >= a.d1) + (co >= a.d2);
-            const int cod = co - (seg == 0 ? 0 : (seg == 1 ? a.d1 : a.d2));
-            float* dp = seg == 0 ? a.dst[0].p : (seg == 1 ? a.dst[1].p : a.dst[2].p);
-            const long long dN = seg == 0 ? a.dst[0].sN : (seg == 1 ? a.dst[1].sN : a.dst[2].sN);
-            const long long dC = seg == 0 ? a.dst[0].sC : (seg == 1 ? a.dst[1].sC : a.dst[2].sC);
-            const long long dH = seg == 0 ? a.dst[0].sH : (seg == 1 ? a.dst[1].sH : a.dst[2].sH);
-            const int dacc = seg == 0 ? a.dst[0].accumulate : (seg == 1 ? a.dst[1].accumulate : a.dst[2].accumulate);
-            const int dws = seg == 0 ? a.dst[0].wshift : (seg == 1 ? a.dst[1].wshift : a.dst[2].wshift);
-#pragma unroll
-            for (int ni = 0; ni < WN; ++ni) {
-                const int pix = (wave * WN + ni) * 32 + l31;
-                const int ho = h0 + pix / TW, wo = w0 + pix % TW;
-                const float v = acc[mi][ni][r] + b;
-                acc[mi][ni][r] = v;
-                if (co < a.Cout && ho < a.Hout && wo < a.Wout && dp) {
-                    float* q = dp + (long long)n * dN + (long long)cod * dC + (long long)ho * dH + ((long long)wo << dws);
-                    const float y = act_apply(fmaf(v, esc, esh), eslope);
-                    *q = dacc ? *q + y : y;
-                }
-            }
-        }
-    }
+        epi_store<MT, WM, WN, (WM * WN >= 4 ? 4 : 8)>(VR_EPI_ARGS(a), acc, smem + Cfg::E_OFF, n, co0, khalf, h0 + TH <= a.Hout && w0 + TW <= a.Wout, hon, won);
     }
     // ---------------- BatchNorm partial statistics (training) -------------------------------------------------
     if (a.part) {
@@ -538,40 +505,95 @@ __global__ __launch_bounds__(256, 3) void conv_dma_s2d_kernel(const ConvArgs a) 
         dma_wait_and_barrier();
     }
 
-    // epilogue: dx[2 ho + ph][2 wo + pw] += acc[ph * 2 + pw]; the pw pair of a row is one 8-byte access when aligned
+    // epilogue: dx[2 ho + ph][2 wo + pw] += acc[ph * 2 + pw]; the pw pair of a row is one 8-byte access when aligned.
+    // Two couts (one accumulator row per lane half) at a time; a group inside the image, inside Cout and inside one 8-byte
+    // aligned destination runs straight-line -- all old values loaded before the first store (conv_epilogue.h has the why).
+    const bool tile_in = 2 * (h0 + TH) <= a.s2_H && 2 * (w0 + TW) <= a.s2_W;
+    long long offq[WN];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        if (co >= a.Cout) continue;
-        const int seg = (co >= a.d1) + (co >= a.d2);
-        const int cod = co - (seg == 0 ? 0 : (seg == 1 ? a.d1 : a.d2));
-        float* dp = seg == 0 ? a.dst[0].p : (seg == 1 ? a.dst[1].p : a.dst[2].p);
-        if (!dp) continue;
-        const long long dN = seg == 0 ? a.dst[0].sN : (seg == 1 ? a.dst[1].sN : a.dst[2].sN);
-        const long long dC = seg == 0 ? a.dst[0].sC : (seg == 1 ? a.dst[1].sC : a.dst[2].sC);
-        const long long dH = seg == 0 ? a.dst[0].sH : (seg == 1 ? a.dst[1].sH : a.dst[2].sH);
-        const int dacc = seg == 0 ? a.dst[0].accumulate : (seg == 1 ? a.dst[1].accumulate : a.dst[2].accumulate);
-        const bool al8 = ((reinterpret_cast<size_t>(dp) | (size_t)(dN * 4) | (size_t)(dC * 4) | (size_t)(dH * 4)) & 7) == 0;
-        float* base = dp + (long long)n * dN + (long long)cod * dC;
+    for (int ni = 0; ni < WN; ++ni) {
+        const int pix = (wave * WN + ni) * 32 + l31;
+        offq[ni] = ((long long)(h0 + pix / TW) << 32) | (unsigned)(w0 + pix % TW);
+    }
 #pragma unroll
-        for (int ni = 0; ni < WN; ++ni) {
-            const int pix = (wave * WN + ni) * 32 + l31;
-            const int ho = h0 + pix / TW, wo = w0 + pix % TW;
+    for (int rg = 0; rg < 16; ++rg) {
+        // row rg of lane half khalf: cout cg0 + 4 khalf
+        constexpr int GR = 1;
+        const int cg0 = co0 + (rg & 3) + 8 * (rg >> 2);
+        const int seg0 = (cg0 >= a.d1) + (cg0 >= a.d2), seg1 = (cg0 + 4 >= a.d1) + (cg0 + 4 >= a.d2);
+        float* const Dp = (seg0 == 0 ? a.dst[0].p : (seg0 == 1 ? a.dst[1].p : a.dst[2].p));
+        const long long sN = (seg0 == 0 ? a.dst[0].sN : (seg0 == 1 ? a.dst[1].sN : a.dst[2].sN));
+        const long long sC = (seg0 == 0 ? a.dst[0].sC : (seg0 == 1 ? a.dst[1].sC : a.dst[2].sC));
+        const long long sH = (seg0 == 0 ? a.dst[0].sH : (seg0 == 1 ? a.dst[1].sH : a.dst[2].sH));
+        const int gacc = (seg0 == 0 ? a.dst[0].accumulate : (seg0 == 1 ? a.dst[1].accumulate : a.dst[2].accumulate));
+        const bool al8g = ((reinterpret_cast<size_t>(Dp) | (size_t)(sN * 4) | (size_t)(sC * 4) | (size_t)(sH * 4)) & 7) == 0;
+        if (tile_in && cg0 + 5 <= a.Cout && seg0 == seg1 && Dp != nullptr && al8g) {
+            const int cseg = seg0 == 0 ? 0 : (seg0 == 1 ? a.d1 : a.d2);
+            float* qb = Dp + (long long)n * sN + (long long)(cg0 - cseg + 4 * khalf) * sC;
+            vr_f32x2 old[GR][WN][2];
+            if (gacc) {
 #pragma unroll
-            for (int ph = 0; ph < 2; ++ph) {
-                const int hf = 2 * ho + ph, wf = 2 * wo;
-                if (hf >= a.s2_H || wf >= a.s2_W) continue;
-                float* q = base + (long long)hf * dH + wf;
-                const float v0 = acc[ph * 2][ni][r], v1 = acc[ph * 2 + 1][ni][r];
-                if (al8 && wf + 1 < a.s2_W) {
-                    vr_f32x2* q2 = reinterpret_cast<vr_f32x2*>(q);
-                    vr_f32x2 o;
-                    o[0] = v0; o[1] = v1;
-                    if (dacc) { const vr_f32x2 old = *q2; o[0] += old[0]; o[1] += old[1]; }
-                    *q2 = o;
-                } else {
-                    q[0] = dacc ? q[0] + v0 : v0;
-                    if (wf + 1 < a.s2_W) q[1] = dacc ? q[1] + v1 : v1;
+                for (int j = 0; j < GR; ++j)
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+                        for (int ph = 0; ph < 2; ++ph)
+                            old[j][ni][ph] = *reinterpret_cast<const vr_f32x2*>(qb + j * sC + (2 * (offq[ni] >> 32) + ph) * sH + 2 * (int)(offq[ni] & 0xffffffffll));
+            } else {
+#pragma unroll
+                for (int j = 0; j < GR; ++j)
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+                        for (int ph = 0; ph < 2; ++ph) { old[j][ni][ph][0] = 0.f; old[j][ni][ph][1] = 0.f; }
+            }
+#pragma unroll
+            for (int j = 0; j < GR; ++j)
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+                    for (int ph = 0; ph < 2; ++ph) {
+                        vr_f32x2 o;
+                        o[0] = acc[ph * 2][ni][rg + j] + old[j][ni][ph][0];
+                        o[1] = acc[ph * 2 + 1][ni][rg + j] + old[j][ni][ph][1];
+                        *reinterpret_cast<vr_f32x2*>(qb + j * sC + (2 * (offq[ni] >> 32) + ph) * sH + 2 * (int)(offq[ni] & 0xffffffffll)) = o;
+                    }
+            continue;
+        }
+#pragma unroll
+        for (int j = 0; j < GR; ++j) {
+            const int r = rg + j;
+            const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            if (co >= a.Cout) continue;
+            const int seg = (co >= a.d1) + (co >= a.d2);
+            const int cod = co - (seg == 0 ? 0 : (seg == 1 ? a.d1 : a.d2));
+            float* dp = seg == 0 ? a.dst[0].p : (seg == 1 ? a.dst[1].p : a.dst[2].p);
+            if (!dp) continue;
+            const long long dN = seg == 0 ? a.dst[0].sN : (seg == 1 ? a.dst[1].sN : a.dst[2].sN);
+            const long long dC = seg == 0 ? a.dst[0].sC : (seg == 1 ? a.dst[1].sC : a.dst[2].sC);
+            const long long dH = seg == 0 ? a.dst[0].sH : (seg == 1 ? a.dst[1].sH : a.dst[2].sH);
+            const int dacc = seg == 0 ? a.dst[0].accumulate : (seg == 1 ? a.dst[1].accumulate : a.dst[2].accumulate);
+            const bool al8 = ((reinterpret_cast<size_t>(dp) | (size_t)(dN * 4) | (size_t)(dC * 4) | (size_t)(dH * 4)) & 7) == 0;
+            float* base = dp + (long long)n * dN + (long long)cod * dC;
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni) {
+                const int ho = (int)(offq[ni] >> 32), wo = (int)(offq[ni] & 0xffffffffll);
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) {
+                    const int hf = 2 * ho + ph, wf = 2 * wo;
+                    if (hf >= a.s2_H || wf >= a.s2_W) continue;
+                    float* q = base + (long long)hf * dH + wf;
+                    const float v0 = acc[ph * 2][ni][r], v1 = acc[ph * 2 + 1][ni][r];
+                    if (al8 && wf + 1 < a.s2_W) {
+                        vr_f32x2* q2 = reinterpret_cast<vr_f32x2*>(q);
+                        vr_f32x2 o;
+                        o[0] = v0; o[1] = v1;
+                        if (dacc) { const vr_f32x2 old = *q2; o[0] += old[0]; o[1] += old[1]; }
+                        *q2 = o;
+                    } else {
+                        q[0] = dacc ? q[0] + v0 : v0;
+                        if (wf + 1 < a.s2_W) q[1] = dacc ? q[1] + v1 : v1;
+                    }
                 }
             }
         }

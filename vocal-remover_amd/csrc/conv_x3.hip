@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "conv_epilogue.h"
 #include "conv_stage.h"
 #include "kernels.h"
 #include "lds_dma.h"
@@ -61,7 +62,8 @@ struct X3Cfg {
     static constexpr int LROWS = TH / 2 + 3, LW = 20, LSLOT = LROWS * LW;
     static constexpr int L_OFF = P_BYTES + 2 * W_BYTES;
     static constexpr int L_BYTES = CK * LSLOT * 4;
-    static constexpr int LDS_BYTES = L_OFF + L_BYTES;
+    static constexpr int E_OFF = L_OFF + L_BYTES;               // epilogue constants of the cout tile: bias, scale, shift [3][MT] fp32
+    static constexpr int LDS_BYTES = E_OFF + 3 * MT * 4;
     static constexpr int OCC = 3 * LDS_BYTES <= 160 * 1024 ? 3 : 2;   // workgroups per CU the register budget must allow
     // vector-memory operations a wave issues per chunk: 8 * NPASS pixel loads (always, also beyond Cin: empty descriptor), and at
     // least NWMIN weight DMAs (the last wave-instruction of the weight slab may be empty for some waves)
@@ -267,6 +269,18 @@ __global__ __launch_bounds__(256, (X3Cfg<MT, TH>::OCC)) void conv_x3_kernel(cons
 
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
+    // epilogue constants of this cout tile (bias; eval: folded BatchNorm scale / shift): loaded FIRST, parked in LDS behind the first
+    // pixel wait -- per-row global loads inside the epilogue were one serialised memory round trip per accumulator row
+    float ecv[3];
+    {
+        const int ec = co0 + (tid & (MT - 1));
+        const int ecc = ec < a.Cout ? ec : a.Cout - 1;
+        const i32x4 rb = make_rsrc(a.bias, a.bias ? 0x7FFFFFF0u : 0u);
+        const i32x4 re = make_rsrc(a.epi, a.epi ? 0x7FFFFFF0u : 0u);
+        ecv[0] = x3_load(rb, ecc * 4);
+        ecv[1] = x3_load(re, ecc * 8);
+        ecv[2] = x3_load(re, ecc * 8 + 4);
+    }
     // prologue: pixels of chunk 0 -> P, weights of chunk 0 and pixels of chunk 1 in flight
 #pragma unroll
     for (int cl = 0; cl < 8; ++cl) load_channel(0, cl, P0{});
@@ -274,6 +288,13 @@ __global__ __launch_bounds__(256, (X3Cfg<MT, TH>::OCC)) void conv_x3_kernel(cons
 #pragma unroll
     for (int cl = 0; cl < 8; ++cl) load_channel(1, cl, P1{});
     wait_pixels(P0{}, std::integral_constant<int, Cfg::NXL + Cfg::NWMIN>{});      // chunk 0's pixels (weights and chunk 1 stay in flight)
+    asm volatile("" : "+v"(ecv[0]), "+v"(ecv[1]), "+v"(ecv[2]));                   // (older loads: landed with them)
+    if (tid < MT) {
+        float* E = reinterpret_cast<float*>(smem_x3 + Cfg::E_OFF);
+        E[tid] = ecv[0];
+        E[MT + tid] = a.epi ? ecv[1] : 1.f;
+        E[2 * MT + tid] = a.epi ? ecv[2] : 0.f;
+    }
     if (any_up) {
         stage_lowres(P0{});
         lds_barrier();
@@ -355,72 +376,14 @@ __global__ __launch_bounds__(256, (X3Cfg<MT, TH>::OCC)) void conv_x3_kernel(cons
         if (k + 1 < nchunk) chunk(k + 1, P1{});
     }
 
-    // ---------------- epilogue (as conv_dma.hip): bias, (eval) BatchNorm + activation, up to three destination segments -------
+    // ---------------- epilogue (conv_epilogue.h): bias, (eval) BatchNorm + activation, up to three destination segments ---------
     if (dbg == 4) return;
-    if (a.d1 >= a.CoutPad) {
-        long long offn[WN];
-        bool okn[WN];
+    {
+        int hon[WN], won[WN];
 #pragma unroll
-        for (int ni = 0; ni < WN; ++ni) {
-            const int ho = h0 + wave * WN + ni, wo = w0 + l31;
-            okn[ni] = ho < a.Hout && wo < a.Wout && a.dst[0].p != nullptr;
-            offn[ni] = (long long)ho * a.dst[0].sH + ((long long)wo << a.dst[0].wshift);
-        }
-        float* dbase = a.dst[0].p + (long long)n * a.dst[0].sN;
-        const int dacc = a.dst[0].accumulate;
-#pragma unroll
-        for (int mi = 0; mi < WM; ++mi) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                const int cc = co < a.Cout ? co : a.Cout - 1;
-                const float b = a.bias ? a.bias[cc] : 0.f;
-                float esc = 1.f, esh = 0.f, eslope = 1.f;
-                if (a.epi) { esc = a.epi[2 * cc]; esh = a.epi[2 * cc + 1]; eslope = a.epi_slope; }
-                float* qrow = dbase + (long long)co * a.dst[0].sC;
-#pragma unroll
-                for (int ni = 0; ni < WN; ++ni) {
-                    const float v = acc[mi][ni][r] + b;
-                    acc[mi][ni][r] = v;
-                    if (co < a.Cout && okn[ni]) {
-                        float* q = qrow + offn[ni];
-                        const float y = act_apply(fmaf(v, esc, esh), eslope);
-                        *q = dacc ? *q + y : y;
-                    }
-                }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int mi = 0; mi < WM; ++mi) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                const int cc = co < a.Cout ? co : a.Cout - 1;
-                const float b = a.bias ? a.bias[cc] : 0.f;
-                float esc = 1.f, esh = 0.f, eslope = 1.f;
-                if (a.epi) { esc = a.epi[2 * cc]; esh = a.epi[2 * cc + 1]; eslope = a.epi_slope; }
-                const int seg = (co >= a.d1) + (co >= a.d2);
-                const int cod = co - (seg == 0 ? 0 : (seg == 1 ? a.d1 : a.d2));
-                float* dp = seg == 0 ? a.dst[0].p : (seg == 1 ? a.dst[1].p : a.dst[2].p);
-                const long long dN = seg == 0 ? a.dst[0].sN : (seg == 1 ? a.dst[1].sN : a.dst[2].sN);
-                const long long dC = seg == 0 ? a.dst[0].sC : (seg == 1 ? a.dst[1].sC : a.dst[2].sC);
-                const long long dH = seg == 0 ? a.dst[0].sH : (seg == 1 ? a.dst[1].sH : a.dst[2].sH);
-                const int dacc = seg == 0 ? a.dst[0].accumulate : (seg == 1 ? a.dst[1].accumulate : a.dst[2].accumulate);
-                const int dws = seg == 0 ? a.dst[0].wshift : (seg == 1 ? a.dst[1].wshift : a.dst[2].wshift);
-#pragma unroll
-                for (int ni = 0; ni < WN; ++ni) {
-                    const int ho = h0 + wave * WN + ni, wo = w0 + l31;
-                    const float v = acc[mi][ni][r] + b;
-                    acc[mi][ni][r] = v;
-                    if (co < a.Cout && ho < a.Hout && wo < a.Wout && dp) {
-                        float* q = dp + (long long)n * dN + (long long)cod * dC + (long long)ho * dH + ((long long)wo << dws);
-                        const float y = act_apply(fmaf(v, esc, esh), eslope);
-                        *q = dacc ? *q + y : y;
-                    }
-                }
-            }
-        }
+        for (int ni = 0; ni < WN; ++ni) { hon[ni] = h0 + wave * WN + ni; won[ni] = w0 + l31; }
+        epi_store<MT, WM, WN>(VR_EPI_ARGS(a), acc, reinterpret_cast<const float*>(smem_x3 + Cfg::E_OFF), n, co0, khalf,
+                              h0 + TH <= a.Hout && w0 + TW <= a.Wout, hon, won);
     }
     // ---------------- BatchNorm partial statistics (training) -------------------------------------------------
     if (a.part) {
