@@ -264,5 +264,123 @@ int main(int argc, char** argv) {
         }
         fflush(stdout);
     }
+    // ---- third part: the conv kernels themselves as victims: each tiling alone, then beside every aggressor, bit-compared ----
+    {
+        printf("conv kernels as victims (output of %d launches beside an aggressor vs the solo output, bit-compared):\n", launches / 4);
+        const size_t nout = (size_t)N * Cout * H * W;
+        float* dout2 = dalloc(nout);
+        std::vector<float> ref(nout), cur(nout);
+        struct Vic { const char* name; int kind, MT, TH, flavour; };      // flavour 1: bias + folded BatchNorm epilogue; 2: + the source seen through the fused x2 upsample
+        const Vic vics[] = {{"conv_x3<64,8>", 0, 64, 8, 0}, {"conv_x3<32,16>", 0, 32, 16, 0}, {"conv_x3<32,8>", 0, 32, 8, 0}, {"conv_dma", 2, 0, 0, 0},
+                            {"x3<64,8> bias+epi", 0, 64, 8, 1}, {"x3<32,16> bias+epi", 0, 32, 16, 1}, {"x3<32,8> bias+epi", 0, 32, 8, 1}, {"dma bias+epi", 2, 0, 0, 1},
+                            {"x3<64,8> up", 0, 64, 8, 2}, {"x3<32,16> up", 0, 32, 16, 2}, {"x3<32,8> up", 0, 32, 8, 2}};
+        std::vector<float> hbias(Cout), hepi(2 * Cout);
+        for (auto& x : hbias) x = nd(rng) * 1e-4f;
+        for (int i = 0; i < Cout; ++i) { hepi[2 * i] = 1.f + 0.1f * nd(rng); hepi[2 * i + 1] = nd(rng) * 1e-4f; }
+        float* dbias = dalloc(Cout);
+        float* depi = dalloc(2 * Cout);
+        VR_HIP(hipMemcpy(dbias, hbias.data(), Cout * 4, hipMemcpyHostToDevice));
+        VR_HIP(hipMemcpy(depi, hepi.data(), 2 * Cout * 4, hipMemcpyHostToDevice));
+        for (const Vic& v : vics) {
+            ConvArgs vb = a;
+            vb.dst[0].p = dout2;
+            if (v.flavour >= 1) { vb.bias = dbias; vb.epi = depi; vb.epi_slope = 0.01f; }
+            if (v.flavour == 2) {                             // the same buffer read as a half-resolution source under the bilinear x2
+                ConvSrc& c2 = vb.src[0];
+                c2.H = H / 2; c2.W = W / 2; c2.sH = W / 2; c2.sC = (long long)(H / 2) * (W / 2); c2.sN = c2.sC * Cin; c2.up = 1;
+                c2.rh = (float)(H / 2 - 1) / (float)(H - 1); c2.rw = (float)(W / 2 - 1) / (float)(W - 1);
+            }
+            X3Tile vt{v.MT, v.TH};
+            DmaTile vdt{};
+            if (v.kind == 0) { vb.x3w = dx3; vb.bf16 = 2; x3_fill_tiling(vb, vt); }
+            if (v.kind == 2) { if (!dma_pick(vb, shp, &vdt)) continue; dma_fill_tiling(vb, vdt); }
+            auto launch_v = [&](hipStream_t st) { if (v.kind == 0) x3_launch_conv(vb, vt, st); else dma_launch_conv(vb, shp, vdt, st); };
+            launch_v(0);
+            VR_HIP(hipDeviceSynchronize());
+            VR_HIP(hipMemcpy(ref.data(), dout2, nout * 4, hipMemcpyDeviceToHost));
+            for (const Agg& g : aggs) {
+                if (g.dbg) continue;
+                ConvArgs b = a;
+                X3Tile t{g.MT, g.TH};
+                int wmt = 0;
+                DmaTile dt{};
+                if (g.kind == 0) { b.x3w = dx3; b.bf16 = 2; x3_fill_tiling(b, t); }
+                if (g.kind == 1) { b.wino = dwino; if (!wino_pick(b, shp, &wmt)) continue; wino_fill_tiling(b, wmt); }
+                if (g.kind == 2) { if (!dma_pick(b, shp, &dt)) continue; dma_fill_tiling(b, dt); }
+                int bad = 0, runs = 0;
+                size_t nbad = 0, firstbad = 0;
+                for (int l = 0; l < launches / 4; ++l) {
+                    for (int rep = 0; rep < 3; ++rep) {
+                        if (g.kind == 0) x3_launch_conv(b, t, sa);
+                        if (g.kind == 1) wino_launch_conv(b, wmt, sa);
+                        if (g.kind == 2) dma_launch_conv(b, shp, dt, sa);
+                    }
+                    VR_HIP(hipMemsetAsync(dout2, 0xff, nout * 4, sb));
+                    launch_v(sb);
+                    VR_HIP(hipMemcpyAsync(cur.data(), dout2, nout * 4, hipMemcpyDeviceToHost, sb));
+                    VR_HIP(hipStreamSynchronize(sb));
+                    ++runs;
+                    size_t nb = 0;
+                    for (size_t i = 0; i < nout; ++i) if (std::memcmp(&cur[i], &ref[i], 4)) { if (!nb && !bad) firstbad = i; ++nb; }
+                    if (nb) { ++bad; nbad += nb; }
+                }
+                VR_HIP(hipDeviceSynchronize());
+                printf("  %-16s beside %-22s: %d of %d runs differ (%zu elements)", v.name, g.name, bad, runs, nbad);
+                if (bad) printf("; first at element %zu (n %zu, cout %zu, h %zu, w %zu)", firstbad, firstbad / ((size_t)Cout * H * W), (firstbad / ((size_t)H * W)) % Cout,
+                                (firstbad / W) % H, firstbad % W);
+                printf("\n");
+                fflush(stdout);
+            }
+        }
+    }
+    // ---- fourth part: the bidirectional LSTM (registers + LDS broadcast of h, compiler-scheduled) as victim ----
+    for (int LHv : {64, 32}) {
+        const int BN = 6, BT = 256, BG = 4 * LHv;
+        std::vector<float> hgx((size_t)BN * 2 * BG * BT), hwf((size_t)BG * LHv), hwr((size_t)BG * LHv);
+        for (auto& v : hgx) v = nd(rng);
+        for (auto& v : hwf) v = nd(rng) * 0.1f;
+        for (auto& v : hwr) v = nd(rng) * 0.1f;
+        float* dgx = dalloc(hgx.size());
+        float* dwf = dalloc(hwf.size());
+        float* dwr = dalloc(hwr.size());
+        float* dho = dalloc((size_t)BN * 2 * LHv * BT);
+        VR_HIP(hipMemcpy(dgx, hgx.data(), hgx.size() * 4, hipMemcpyHostToDevice));
+        VR_HIP(hipMemcpy(dwf, hwf.data(), hwf.size() * 4, hipMemcpyHostToDevice));
+        VR_HIP(hipMemcpy(dwr, hwr.data(), hwr.size() * 4, hipMemcpyHostToDevice));
+        const size_t nh = (size_t)BN * 2 * LHv * BT;
+        std::vector<float> ref(nh), cur(nh);
+        launch_bilstm(dgx, dwf, dwr, dho, BN, BT, LHv, 0);
+        VR_HIP(hipDeviceSynchronize());
+        VR_HIP(hipMemcpy(ref.data(), dho, nh * 4, hipMemcpyDeviceToHost));
+        for (const Agg& g : aggs) {
+            if (g.dbg) continue;
+            ConvArgs b = a;
+            X3Tile t{g.MT, g.TH};
+            int wmt = 0;
+            DmaTile dt{};
+            if (g.kind == 0) { b.x3w = dx3; b.bf16 = 2; x3_fill_tiling(b, t); }
+            if (g.kind == 1) { b.wino = dwino; if (!wino_pick(b, shp, &wmt)) continue; wino_fill_tiling(b, wmt); }
+            if (g.kind == 2) { if (!dma_pick(b, shp, &dt)) continue; dma_fill_tiling(b, dt); }
+            int bad = 0, runs = 0;
+            size_t nbad = 0;
+            for (int l = 0; l < launches / 4; ++l) {
+                for (int rep = 0; rep < 3; ++rep) {
+                    if (g.kind == 0) x3_launch_conv(b, t, sa);
+                    if (g.kind == 1) wino_launch_conv(b, wmt, sa);
+                    if (g.kind == 2) dma_launch_conv(b, shp, dt, sa);
+                }
+                launch_bilstm(dgx, dwf, dwr, dho, BN, BT, LHv, sb);
+                VR_HIP(hipMemcpyAsync(cur.data(), dho, nh * 4, hipMemcpyDeviceToHost, sb));
+                VR_HIP(hipStreamSynchronize(sb));
+                ++runs;
+                size_t nb = 0;
+                for (size_t i = 0; i < nh; ++i) if (std::memcmp(&cur[i], &ref[i], 4)) ++nb;
+                if (nb) { ++bad; nbad += nb; }
+            }
+            VR_HIP(hipDeviceSynchronize());
+            printf("  bilstm H=%-3d     beside %-22s: %d of %d runs differ (%zu elements)\n", LHv, g.name, bad, runs, nbad);
+            fflush(stdout);
+        }
+    }
     return 0;
 }

@@ -71,6 +71,10 @@ struct EpiGroup {
                 const int cl = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
                 eb[j] = E[cl]; esc[j] = E[MT + cl]; esh[j] = E[2 * MT + cl];
             }
+            // full wait before the first consumer of the LDS reads (hardware fact 5)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < G; ++j) asm volatile("" : "+v"(eb[j]), "+v"(esc[j]), "+v"(esh[j]));
             if (tile_in && cg0 + 2 * G <= e_Cout && seg0 == seg1 && Dp != nullptr) {
                 const int cseg = seg0 == 0 ? 0 : (seg0 == 1 ? e_d1 : e_d2);
                 const long long sN = VR_DST_FIELD(seg0, sN);
