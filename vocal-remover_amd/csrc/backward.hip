@@ -246,10 +246,26 @@ __global__ __launch_bounds__(256) void upsample_bwd_tiled_kernel(const float* __
     const int H2 = 2 * H, W2 = 2 * W;
     const float* src = dhi + (long long)plane * H2 * W2;
     const int hb = 2 * i0 - 2, wb = 2 * j0 - 2;
-    for (int e = threadIdx.x; e < PH * PW; e += 256) {
+    // all loads of the thread issued before the first use: clamped addresses, masked afterwards (a load behind its own guard gets
+    // a vmcnt(0) from hipcc -- five serial memory round trips per thread)
+    constexpr int NL = (PH * PW + 255) / 256;
+    float pv[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        const int e = threadIdx.x + 256 * k;
+        const int ec = e < PH * PW ? e : PH * PW - 1;
+        const int r = ec / PW, q = ec - r * PW;
+        int h = hb + r, w = wb + q;
+        h = h < 0 ? 0 : (h >= H2 ? H2 - 1 : h);
+        w = w < 0 ? 0 : (w >= W2 ? W2 - 1 : w);
+        pv[k] = src[(long long)h * W2 + w];
+    }
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        const int e = threadIdx.x + 256 * k;
         const int r = e / PW, q = e - r * PW;
         const int h = hb + r, w = wb + q;
-        patch[r * PP + q] = (h >= 0 && h < H2 && w >= 0 && w < W2) ? src[(long long)h * W2 + w] : 0.f;
+        if (e < PH * PW) patch[r * PP + q] = (h >= 0 && h < H2 && w >= 0 && w < W2) ? pv[k] : 0.f;
     }
     __syncthreads();
     const int ti = threadIdx.x >> 5, tj = threadIdx.x & 31;
