@@ -14,8 +14,8 @@ between barriers after the headline region:
     "train"  configs[3]: the train.py step (fwd + L1 + bwd [+ RCCL all-reduce of the flat gradient bucket over the N
              ranks] + Adam), batch 16 x [2,1025,256] per GPU
 plus `roofline` (dominant kernel family = the MFMA convs: algorithmic FLOPs / HIP-event time per launch, summed over the
-launches of ONE EXTRA step run with every kernel serialised on one stream -- not the timed steps, which overlap lanes and
-streams; HBM traffic per launch from the committed rocprofv3 PMC passes) and `cpu_baseline` (the CPU oracle -- a port of
+launches of the fastest of THREE EXTRA steps run with every kernel serialised on one stream -- not the timed steps, which overlap
+lanes and streams; HBM traffic per launch from the committed rocprofv3 PMC passes) and `cpu_baseline` (the CPU oracle -- a port of
 the reference's path, kind "port" -- timed on this box's host cores, N=1 only).
 
 Arithmetic: fp32 throughout; the 3x3 stride-1 convolutions form every fp32 product from six bf16 products of three-way
@@ -250,7 +250,9 @@ def main():
         return cms.value, cfl.value, cn.value, cby.value
 
     def roofline(step, kernel, pmc_name):
-        cms, cfl, cn, cby = conv_profile(step)
+        # three profiled steps, the fastest one is reported: a single serialised step is exposed to one-off stalls (seen once: a tta
+        # step at 2x its usual kernel time while the timed steps of the same run were normal)
+        cms, cfl, cn, cby = min((conv_profile(step) for _ in range(3)), key=lambda r: r[0])
         achieved = cfl / (cms * 1e-3) / 1e12 if cms > 0 else 0.0
         traffic, src = None, None
         path = os.path.join(ROOT, 'profiles', pmc_name)
@@ -259,7 +261,7 @@ def main():
             src = 'profiles/' + pmc_name
         return {'bound': 'mfma', 'kernel': kernel, 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
-                'source': 'ONE EXTRA step after the timed region, every launch serialised on one stream and bracketed by HIP events on '
+                'source': 'the fastest of THREE EXTRA steps after the timed region, every launch serialised on one stream and bracketed by HIP events on '
                           'the library\'s stream (the timed steps overlap 2 lanes x 2 streams, so kernel_ms_per_step can exceed ms_per_step)',
                 'peak_note': 'peak = fp32 MFMA (v_mfma_f32_32x32x2_f32 = the fp32 vector rate).  In mfma_mode 2 the 3x3 stride-1 convs run '
                              'on the bf16 pipe instead: 2500 TFLOP/s dense / 6 products = %.0f fp32-equivalent TFLOP/s at 2.4 GHz -- the '
