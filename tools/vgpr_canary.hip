@@ -120,6 +120,77 @@ __global__ __launch_bounds__(256) void whh_variant_kernel(const float* __restric
     }
 }
 
+// Synthetic aggressors (hardware fact 5: which KIND of neighbour disturbs the LDS -> VALU chain of the victim?), each ~64 registers so
+// that its waves share SIMDs with the victim's: kind 3 streams global memory into registers (float4 loads, 8 in flight), kind 4
+// only moves global memory into LDS by DMA, kind 5 only runs VALU FMAs, kind 6 streams LDS reads.
+__global__ __launch_bounds__(256) void agg_vmem_kernel(const float4* __restrict__ src, size_t n4, float* __restrict__ sink, int iters) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = src[(i + (size_t)k * 65536) % n4];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w; }
+        i += 8 * 65536 + 17;
+    }
+    if (s.x + s.y + s.z + s.w == 12345.678f) sink[0] = s.x;
+}
+__global__ __launch_bounds__(256) void agg_dma_kernel(const float* __restrict__ src, size_t nbytes, int iters) {
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    const unsigned lds0 = (unsigned)(size_t)lds_dyn;
+    const i32x4 r = make_rsrc(src, (unsigned)(nbytes > 0x7FFFFFF0ull ? 0x7FFFFFF0ull : nbytes));
+    unsigned off = (blockIdx.x * 256 + threadIdx.x) * 16;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dma16(lds0 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 4096 + k * 1024, off + k * 4194304u, r);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        off += 16 * 65536;
+    }
+}
+__global__ __launch_bounds__(256) void agg_valu_kernel(float* __restrict__ sink, int iters) {
+    float a0 = threadIdx.x, a1 = 1.f, a2 = 2.f, a3 = 3.f;
+    for (int it = 0; it < iters * 64; ++it) { a0 = fmaf(a0, 1.0001f, a1); a1 = fmaf(a1, 0.9999f, a2); a2 = fmaf(a2, 1.0002f, a3); a3 = fmaf(a3, 0.9998f, a0); }
+    if (a0 + a1 + a2 + a3 == 12345.678f) sink[0] = a0;
+}
+__global__ __launch_bounds__(256) void agg_lds_kernel(float* __restrict__ sink, int iters) {
+    __shared__ float buf[8192];
+    for (int i = threadIdx.x; i < 8192; i += 256) buf[i] = (float)i;
+    __syncthreads();
+    float s = 0.f;
+    for (int it = 0; it < iters * 8; ++it) {
+        const float4 v = *reinterpret_cast<const float4*>(&buf[((threadIdx.x * 4 + it * 1024) & 8188)]);
+        s += v.x + v.y + v.z + v.w;
+    }
+    if (s == 12345.678f) sink[0] = s;
+}
+
+// kind 7 / 8: nothing but matrix instructions (bf16 32x32x16 / fp32 32x32x2), two independent accumulators per wave
+__global__ __launch_bounds__(256) void agg_mfma_bf16_kernel(float* __restrict__ sink, int iters) {
+    vr_bf16x8 av, bv;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { av[i] = (short)(0x3f80 + threadIdx.x + i); bv[i] = (short)(0x3f00 + i); }
+    f32x16 c0, c1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+    for (int it = 0; it < iters * 32; ++it) {
+        c0 = mfma_bf16x16(av, bv, c0);
+        c1 = mfma_bf16x16(bv, av, c1);
+    }
+    if (c0[0] + c1[3] == 12345.678f) sink[0] = c0[0];
+}
+__global__ __launch_bounds__(256) void agg_mfma_f32_kernel(float* __restrict__ sink, int iters) {
+    const float av = 1.f + threadIdx.x * 1e-3f, bv = 0.5f;
+    f32x16 c0, c1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+    for (int it = 0; it < iters * 16; ++it) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, c1, 0, 0, 0);
+    }
+    if (c0[0] + c1[3] == 12345.678f) sink[0] = c0[0];
+}
+
 static float* dalloc(size_t n) { float* p; VR_HIP(hipMalloc(&p, (n ? n : 1) * 4)); return p; }
 
 int main(int argc, char** argv) {
@@ -181,6 +252,19 @@ int main(int argc, char** argv) {
         {"conv_x3<64,8> dbg1 (no pixel loads)", 0, 64, 8, 1}, {"conv_x3<64,8> dbg3 (no split pass)", 0, 64, 8, 3},
         {"conv_x3<64,8> dbg4 (no epilogue)", 0, 64, 8, 4},
         {"conv_wino", 1, 0, 0, 0}, {"conv_dma", 2, 0, 0, 0},
+        {"synthetic: global -> register stream", 3, 0, 0, 0}, {"synthetic: global -> LDS DMA only", 4, 0, 0, 0},
+        {"synthetic: VALU only", 5, 0, 0, 0}, {"synthetic: LDS reads only", 6, 0, 0, 0},
+        {"synthetic: bf16 MFMA only", 7, 0, 0, 0}, {"synthetic: fp32 MFMA only", 8, 0, 0, 0},
+    };
+    float* dsink = dalloc(16);
+    auto launch_synth = [&](int kind, hipStream_t st) {
+        const size_t n4 = hx.size() / 4;
+        if (kind == 3) hipLaunchKernelGGL(agg_vmem_kernel, dim3(2048), dim3(256), 0, st, reinterpret_cast<const float4*>(dx), n4, dsink, 24);
+        if (kind == 4) hipLaunchKernelGGL(agg_dma_kernel, dim3(2048), dim3(256), 16384, st, dx, hx.size() * 4, 24);
+        if (kind == 5) hipLaunchKernelGGL(agg_valu_kernel, dim3(2048), dim3(256), 0, st, dsink, 24);
+        if (kind == 6) hipLaunchKernelGGL(agg_lds_kernel, dim3(2048), dim3(256), 0, st, dsink, 24);
+        if (kind == 7) hipLaunchKernelGGL(agg_mfma_bf16_kernel, dim3(2048), dim3(256), 0, st, dsink, 24);
+        if (kind == 8) hipLaunchKernelGGL(agg_mfma_f32_kernel, dim3(2048), dim3(256), 0, st, dsink, 24);
     };
     for (const Agg& g : aggs) {
         VR_HIP(hipMemset(dcount, 0, 4));
@@ -200,6 +284,7 @@ int main(int argc, char** argv) {
             if (g.kind == 0) x3_launch_conv(b, t, sa);
             if (g.kind == 1) wino_launch_conv(b, wmt, sa);
             if (g.kind == 2) dma_launch_conv(b, shp, dt, sa);
+            if (g.kind >= 3) launch_synth(g.kind, sa);
             // a fresh wave of canaries every few conv launches: 32 blocks as the weight_hh kernel, and a chip-filling one
             if (l % 2 == 0) hipLaunchKernelGGL(canary_kernel, dim3(l % 4 == 0 ? 32 : 512), dim3(256), 0, sb, dlog, dcount, 300);
         }
@@ -219,6 +304,7 @@ int main(int argc, char** argv) {
             if (g.kind == 0) x3_launch_conv(b, t, sa);
             if (g.kind == 1) wino_launch_conv(b, wmt, sa);
             if (g.kind == 2) dma_launch_conv(b, shp, dt, sa);
+            if (g.kind >= 3) launch_synth(g.kind, sa);
             if (l % 4 == 1) {
                 const dim3 wgrid((4 * LH + 15) / 16, 2, (LH + 63) / 64);
                 if (variant < 0) launch_lstm_whh_grad(ddg, dh, ddw, ddw + (size_t)LG * LH, LN, LT, LH, 0, dpart, sb);
@@ -314,6 +400,7 @@ int main(int argc, char** argv) {
                         if (g.kind == 0) x3_launch_conv(b, t, sa);
                         if (g.kind == 1) wino_launch_conv(b, wmt, sa);
                         if (g.kind == 2) dma_launch_conv(b, shp, dt, sa);
+            if (g.kind >= 3) launch_synth(g.kind, sa);
                     }
                     VR_HIP(hipMemsetAsync(dout2, 0xff, nout * 4, sb));
                     launch_v(sb);
@@ -368,6 +455,7 @@ int main(int argc, char** argv) {
                     if (g.kind == 0) x3_launch_conv(b, t, sa);
                     if (g.kind == 1) wino_launch_conv(b, wmt, sa);
                     if (g.kind == 2) dma_launch_conv(b, shp, dt, sa);
+            if (g.kind >= 3) launch_synth(g.kind, sa);
                 }
                 launch_bilstm(dgx, dwf, dwr, dho, BN, BT, LHv, sb);
                 VR_HIP(hipMemcpyAsync(cur.data(), dho, nh * 4, hipMemcpyDeviceToHost, sb));
