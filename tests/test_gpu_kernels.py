@@ -78,7 +78,9 @@ def test_batchnorm_train_forward_stats_and_backward(handle, shape, slope, use_po
     close(out[5], rv, 'running_var (unbiased)', 1e-5)
 
 
-@pytest.mark.parametrize('N,T,H', [(2, 128, 64), (3, 128, 32), (1, 40, 16)])
+# (11, 72, 64): eleven samples over the eight sample slices of lstm_whh_grad_kernel, a ragged last frame block; (16, 256, 32): the
+# benched batch
+@pytest.mark.parametrize('N,T,H', [(2, 128, 64), (3, 128, 32), (1, 40, 16), (11, 72, 64), (16, 256, 32)])
 def test_bilstm_forward_bptt_and_whh_gradient(handle, N, T, H):
     nat, h = handle
     g = torch.Generator().manual_seed(T + H)
