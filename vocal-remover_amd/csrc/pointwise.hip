@@ -9,6 +9,11 @@ namespace vr {
 
 __device__ __forceinline__ float act1(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+// (scale, shift) = (1, 0) and a post factor of 1 for tensors without them: lets a kernel load its constants unconditionally, in the
+// same burst as its pixels (a load behind `if (aff)` is followed by a vmcnt(0): one extra memory round trip per constant)
+__device__ const float kIdentityAffine[2] = {1.f, 0.f};
+__device__ const float kOne[1] = {1.f};
+
 __device__ __forceinline__ void load_aff(const Tensor& x, int h, int c, float& sc, float& sh) {
     const float* aff = (h < x.hsplit) ? x.aff0 : x.aff1;
     sc = 1.f; sh = 0.f;
@@ -306,18 +311,27 @@ __global__ __launch_bounds__(256) void upsample2x_rows_kernel(Tensor x, float* _
     const float h1l = h1r - (float)h1, h0l = 1.f - h1l;
     const float* r0 = x.p + (long long)n * x.sN + (long long)c * x.sC + (long long)h1 * x.sH;
     const float* r1 = r0 + (long long)h1p * x.sH;
-    float sc0, sh0, sc1, sh1;
-    load_aff(x, h1, c, sc0, sh0);
-    load_aff(x, h1 + h1p, c, sc1, sh1);
-    const float post = x.post ? x.post[n * x.C + c] : 1.f;
+    // the affine of the two source rows and the dropout factor through unconditional pointers: one burst with the eight pixels
+    const float* af0 = (h1 < x.hsplit) ? x.aff0 : x.aff1;
+    const float* af1 = (h1 + h1p < x.hsplit) ? x.aff0 : x.aff1;
+    const float* ap0 = af0 ? af0 + 2 * c : kIdentityAffine;
+    const float* ap1 = af1 ? af1 + 2 * c : kIdentityAffine;
+    const float* pp = x.post ? x.post + n * x.C + c : kOne;
     // source columns of the quad: floor(rw * wi) for wi = 4q .. 4q+3 lie in [wb, wb + 2] with wb = floor(rw * 4q); + 1 neighbour
     const int wb = (int)(rw * (float)(4 * q));
-    float a[4], b[4];
+    float ra[4], rb[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int ws = wb + j < x.W ? wb + j : x.W - 1;
-        a[j] = act1(fmaf(r0[ws], sc0, sh0), x.slope);
-        b[j] = act1(fmaf(r1[ws], sc1, sh1), x.slope);
+        ra[j] = r0[ws];
+        rb[j] = r1[ws];
+    }
+    const float sc0 = ap0[0], sh0 = ap0[1], sc1 = ap1[0], sh1 = ap1[1], post = pp[0];
+    float a[4], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        a[j] = act1(fmaf(ra[j], sc0, sh0), x.slope);
+        b[j] = act1(fmaf(rb[j], sc1, sh1), x.slope);
     }
     float o[4];
 #pragma unroll
