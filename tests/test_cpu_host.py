@@ -94,15 +94,6 @@ def test_make_padding_and_crop_center(built):
         built.spec_utils.crop_center(b, a)
 
 
-def test_dropin_shadow_modules_resolve(built):
-    import importlib.util
-    p = os.path.join(ROOT, 'vocal-remover_amd', 'dropin', 'lib', 'nets.py')
-    spec = importlib.util.spec_from_file_location('dropin_nets_probe', p)
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    assert mod.CascadedNet is built.nets.CascadedNet
-
-
 def _ref_merge(reference_lib):
     import importlib
     return importlib.import_module('lib.spec_utils').merge_artifacts

@@ -13,6 +13,7 @@ batch-2 full-net test never reaches, and the train executor runs three streams. 
     boundaries, against an fp64 reference.
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -240,3 +241,71 @@ def test_split_bf16_mode_is_fp32_exact_on_special_values(vr, full16, kind, shape
     print('%s %s: max error / scale  ' % (kind, shape) + '  '.join('%s %.3e' % kv for kv in errs.items()))
     # as exact as an fp32 DIRECT convolution (the Winograd form sums 2.25x fewer products and sits below all of them)
     assert errs['split-bf16'] <= 1.5 * max(errs['fp32 MFMA direct'], errs['torch cpu fp32']) + 1e-7
+
+
+def test_b16_train_step_vs_cpu_oracle(vr, full16):
+    """The BENCHED train configuration against the oracle ("missing" 4): full net, batch 16 x [2,1025,256], one body of
+    train.py:77-96 -- loss, train-mode mask, every BatchNorm running statistic, every gradient -- vs the fp32 CPU oracle at the
+    SAME batch (~40 GB of host memory, ~30-60 s; the fp64 oracle at batch 16 would need ~95 GB and minutes, it calibrates the
+    batch-2 test in test_gpu_configs.py instead).  Both sides round in fp32 in different orders, so the gradient bars are those
+    of two fp32 evaluations against each other: per tensor rel-L2 <= 6e-2 (>= 16 elements), median <= 3e-2, the vector of
+    per-tensor gradient norms within 2 %, global cosine >= 0.999 (measured: median 2.6e-2, norms within 1.1 %, cosine 0.99964); loss 2e-6 (measured: equal to 8 digits); mask 5e-4 (the GPU's own two fp32 modes differ by
+    1.4e-4 at this batch, test_b16_fp32_modes_agree); running statistics 1e-4 of scale.  Both multiply modes, same bars."""
+    from oracle import cascaded_net
+    model, sd, X, y, masks = full16
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    Xc, yc = X.cpu(), y.cpu()
+    sd32 = weights.clone_state_dict(sd)
+    loss_c, g_c = train_step.loss_and_grads(sd32, Xc, yc, n_fft=N_FFT, dropout=masks)          # updates sd32's running stats
+    with torch.no_grad():
+        mask_c = cascaded_net.forward(Xc, weights.clone_state_dict(sd), N_FFT, training=True, update_running=False, dropout=masks)
+    for mode in (0, 2):
+        try:
+            model.load_state_dict(sd)
+            model.set_option('mfma_mode', mode)
+            model.train()
+            model.set_dropout_masks(masks)
+            model.zero_grad()
+            loss, mask = model.train_step(X, y, 1, return_mask=True)
+            grads = model.grads()
+            state = model.state_dict()
+        finally:
+            model.set_dropout_masks(None)
+            model.set_option('mfma_mode', -1)
+            model.load_state_dict(sd)
+            model.eval()
+        assert abs(loss - loss_c) < 2e-6, (mode, loss, loss_c)
+        e_mask = float((mask.cpu() - mask_c).abs().max())
+        rel, bad, dot, n_g, n_c, norm_dev = [], [], 0.0, 0.0, 0.0, 0.0
+        for k in g_c:
+            if k.endswith('dense.0.bias'):
+                assert float(grads[k].abs().max()) < 1e-6, k           # exact gradient 0: a BatchNorm follows the bias
+                continue
+            a, b = grads[k].double(), g_c[k].double()
+            e = float((a - b).norm() / (b.norm() + 1e-30))
+            rel.append((e, k))
+            dot += float((a * b).sum()); n_g += float((a * a).sum()); n_c += float((b * b).sum())
+            if b.numel() >= 16:
+                norm_dev = max(norm_dev, abs(float(a.norm() / (b.norm() + 1e-30)) - 1.0))
+                if e > 6e-2:
+                    bad.append('%s %.3e' % (k, e))
+            elif e > 1.0:
+                # the 1-element BatchNorm weight / bias of an LSTM squeeze conv: a sum of 0.5 M products of either sign that cancels
+                # to a few per cent of its terms, so the 2-3 % disagreement of two fp32 evaluations upstream shows as tens of per
+                # cent here (measured 0.60 on stg1_low ...conv.1.weight; batch 2 vs fp64: CPU fp32 0.06, GPU 0.15-0.35); sign and
+                # magnitude must hold, the reduction itself is pinned at 1e-4 against fp64 in test_gpu_kernels.py (bn_backward)
+                bad.append('%s %.3e (small tensor)' % (k, e))
+        rel.sort(reverse=True)
+        med = float(np.median([r[0] for r in rel]))
+        cos = dot / (n_g * n_c) ** 0.5
+        print('mfma_mode %d, batch 16 vs fp32 CPU oracle: loss %.8f / %.8f; mask max-abs %.2e; gradient rel-L2 median %.2e, worst %s '
+              '%.2e; per-tensor norm deviation max %.2e; global cosine %.6f' % (mode, loss, loss_c, e_mask, med, rel[0][1], rel[0][0],
+                                                                                norm_dev, cos))
+        assert not bad, '\n'.join(bad)
+        assert med < 3e-2 and cos > 0.999 and norm_dev < 2e-2 and e_mask < 5e-4
+        for k in sd32:
+            if k.endswith('running_mean') or k.endswith('running_var'):
+                scale = float(sd32[k].abs().max()) + 1e-6
+                assert float((state[k] - sd32[k]).abs().max()) < 1e-4 * scale, k
+            elif k.endswith('num_batches_tracked'):
+                assert int(state[k]) == int(sd32[k]), k

@@ -1,10 +1,16 @@
-import os as _os
-import sys as _sys
-
-_root = _os.path.dirname(_os.path.dirname(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))))
-if _root not in _sys.path:
-    _sys.path.insert(0, _root)
-import __graft_entry__ as _ge  # noqa: E402
-
-_pkg = _ge.load_package()
+"""Shadow of the reference's lib/nets.py: the MI355X implementations; names this package does not provide fall through to the
+checkout's own lib/nets.py (module __getattr__), e.g. image dumps and the torch layer classes, which are outside the hot path."""
+from lib import _passthrough, _pkg  # noqa: F401  (importing `lib` loads vocal_remover_amd)
 from vocal_remover_amd.nets import *  # noqa: E402,F401,F403
+import vocal_remover_amd.nets as _impl  # noqa: E402
+
+
+def __getattr__(name):
+    if name.startswith('__'):
+        raise AttributeError(name)
+    if hasattr(_impl, name):
+        return getattr(_impl, name)
+    try:
+        return getattr(_passthrough('nets'), name)
+    except ImportError as e:
+        raise AttributeError('lib.nets.%s: not part of the MI355X path and %s' % (name, e))

@@ -30,6 +30,22 @@ def crop_center(h1, h2):
     return h1[:, :, :, s_time:e_time]
 
 
+def merge_artifacts(y_mask, thres=0.05, min_range=64, fade_size=32):
+    """lib/spec_utils.py:60-93 with numpy in / numpy out, for callers that keep the reference's own `Separator._postprocess`
+    (inference.py:26-30).  The O(T) run logic (which frames get blended, the linear fades, the IndexError on a mask with no
+    frame above `thres`, the ValueError on min_range < 2 * fade_size) is the library's host half of --postprocess -- the same
+    code `vr_separate(..., postprocess)` runs; the blend `y_mask += weight * (1 - y_mask)` is applied in place, like there.
+    (`Separator(postprocess=True)` of this package does all of it on the device instead.)"""
+    y_mask = np.asarray(y_mask)
+    T = y_mask.shape[2]
+    frame_min = np.ascontiguousarray(y_mask.min(axis=(0, 1)), dtype=np.float32)
+    weight = np.empty(T, dtype=np.float32)
+    native.check(native.lib().vr_debug_merge_artifacts_weight(native.np_ptr(frame_min), T, float(thres), int(min_range),
+                                                              int(fade_size), native.np_ptr(weight)))
+    y_mask += weight.astype(y_mask.dtype)[None, None, :] * (1 - y_mask)
+    return y_mask
+
+
 def wave_to_spectrogram(wave, hop_length, n_fft):
     """lib/spec_utils.py:26-31: [2, L] float32 -> [2, n_fft/2+1, 1 + L//hop] complex64."""
     wave = np.ascontiguousarray(np.asarray(wave, dtype=np.float32))
