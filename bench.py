@@ -13,10 +13,18 @@ between barriers after the headline region:
     "tta"    configs[2]: the same song through Separator.separate_tta (23 crops)
     "train"  configs[3]: the train.py step (fwd + L1 + bwd [+ RCCL all-reduce of the flat gradient bucket over the N
              ranks] + Adam), batch 16 x [2,1025,256] per GPU
-plus `roofline` (dominant kernel family = the MFMA convs: algorithmic FLOPs / HIP-event time per launch, summed over the
-launches of the fastest of THREE EXTRA steps run with every kernel serialised on one stream -- not the timed steps, which overlap
-lanes and streams; HBM traffic per launch from the committed rocprofv3 PMC passes) and `cpu_baseline` (the CPU oracle -- a port of
-the reference's path, kind "port" -- timed on this box's host cores, N=1 only).
+plus `roofline` and `cpu_baseline` (the CPU oracle -- a port of the reference's path, kind "port" -- timed on this box's host
+cores, N=1 only).
+
+`roofline` is measured live: the fastest of THREE EXTRA steps after the timed region, run with every kernel serialised on one
+stream and EVERY kernel launch bracketed by HIP events on the stream it is launched on (vr_profile_begin / vr_profile_report).
+`roofline.classes` lists each kernel class against ITS OWN ceiling -- conv_x3 (3x3 stride-1, six bf16 products per fp32 product)
+against the bf16 matrix pipe (2500 TFLOP/s dense, achieved = 6 x the direct-convolution FLOPs / time), the fp32-MFMA convolutions
+and weight gradients against 157.3 TFLOP/s, the 1x1 / thin / element-wise / STFT kernels against 8 TB/s of HBM with their
+algorithmic bytes -- a class is priced against whichever of its two roofs (FLOPs / peak, bytes / 8 TB/s) is the longer time.
+`roofline.frac` is the DOMINANT class's own fraction; `frac_fp32_equivalent` keeps the round-1..3 aggregate (direct-conv FLOPs of
+the whole conv family / fp32-MFMA peak).  `roofline.kernels` carries the per-kernel rows the classes are summed from; the
+rocprofv3 summaries of the same command are in profiles/.  HBM traffic per launch comes from the committed rocprofv3 PMC passes.
 
 Arithmetic: fp32 throughout; the 3x3 stride-1 convolutions form every fp32 product from six bf16 products of three-way
 split operands on the bf16 matrix pipe (mfma_mode 2, the library default: error against fp64 = an fp32 direct
@@ -43,6 +51,28 @@ sys.path.insert(0, ROOT)
 import __graft_entry__  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense bf16 matrix peak (never the 2:1-sparsity figure)
+HBM_PEAK_TBS = 8.0
+PROFILE_ROUND = 'r04'              # profiles/<round>_{infer,tta,train}_pmc.json: the PMC passes `traffic` is read from
+
+# kernel name -> (class label, matrix pipe or None).  Everything not listed is priced against HBM when the library noted algorithmic
+# bytes for it, and reported as 'other' (latency / launch bound: LSTM recurrence, finalize kernels, descriptor refreshes) when not.
+KERNEL_CLASSES = (
+    ('conv_x3_kernel', 'conv_x3: 3x3 stride-1 forward + data gradient, fp32 products from six bf16 products', 'bf16'),
+    ('wgrad_wino_kernel', 'wgrad_wino: 3x3 stride-1 weight gradient, Winograd F(3x3,2x2), fp32 MFMA', 'fp32'),
+    ('conv_wino_kernel', 'conv_wino: 3x3 stride-1, Winograd F(2x2,3x3), fp32 MFMA (mfma_mode 0)', 'fp32'),
+    ('conv_dma_kernel<1,', 'conv 1x1 (ASPP, tails, LSTM projection / dense), fp32 MFMA', 'fp32'),
+    ('wgrad_gemm_kernel', 'conv 1x1 weight gradient, fp32 MFMA GEMM', 'fp32'),
+    ('wgrad_mfma_kernel<1,', 'conv 1x1 weight gradient, fp32 MFMA GEMM', 'fp32'),
+    ('conv_dma_kernel<3, 2', 'conv 3x3 stride-2 forward, fp32 MFMA', 'fp32'),
+    ('conv_dma_s2d_kernel', 'conv 3x3 stride-2 data gradient, fp32 MFMA', 'fp32'),
+    ('wgrad_ws_kernel', 'conv 3x3 stride-2 / leftover weight gradient, fp32 MFMA', 'fp32'),
+    ('conv_dma_kernel<3,', 'conv 3x3 dilated (ASPP) + 16-wide stride-1, fp32 MFMA', 'fp32'),
+    ('wgrad_mfma_kernel<3,', 'conv 3x3 dilated / 16-wide weight gradient, fp32 MFMA', 'fp32'),
+    ('conv_thin_kernel', 'conv 3x3 with <= 16 output channels, fp32 MFMA 16x16x4', 'fp32'),
+    ('conv_ws_kernel', 'conv fused-loader leftovers, fp32 MFMA', 'fp32'),
+    ('conv_mfma_kernel', 'conv fused-loader leftovers, fp32 MFMA', 'fp32'),
+)
 SR, N_FFT, HOP, CROP = 44100, 2048, 1024, 256
 
 
@@ -128,14 +158,14 @@ def _host_memory_gb():
 
 
 def cpu_baseline_train(sd, want_batch=16):
-    """CPU oracle train step (fwd + L1 + bwd + Adam) at the largest batch <= the GPU's that fits the host's memory
-    (autograd keeps ~2.6 GB of activations per sample in fp32) and a ~30 s budget."""
+    """CPU oracle train step (fwd + L1 + bwd + Adam) at the GPU's batch (16: ~40 GB of host memory, ~30-60 s on 16 cores), halved
+    only while the host's memory does not hold it (autograd keeps ~2.6 GB of activations per sample in fp32)."""
     from oracle import train_step as ots, weights as ow
     cores = usable_cores()
     torch.set_num_threads(cores)
     mem = _host_memory_gb()
     B = want_batch
-    while B > 2 and (3.0 * B + 4.0 > 0.7 * mem or B > 8):     # 8 samples ~ 25 s on 16 cores: the bounded-sample budget
+    while B > 2 and 3.0 * B + 4.0 > 0.7 * mem:                # ~2.6 GB of saved activations per sample
         B //= 2
     sd = ow.clone_state_dict(sd)
     X, y = ots.synth_batch(B, T=CROP, n_fft=N_FFT, seed=0)
@@ -146,17 +176,9 @@ def cpu_baseline_train(sd, want_batch=16):
     dt = time.perf_counter() - t0
     return {'value': B * CROP / dt, 'unit': 'spectrogram-frames/sec', 'cores': cores, 'kind': 'port',
             'sample': 'one oracle train step (port: autograd over the restated net + restated Adam) at batch %d x [2,1025,256] '
-                      '-- the largest power of two <= 16 that fits %.0f GB of host memory and the ~30 s sample budget (the GPU runs '
-                      'batch %d) -- %.1f s wall' % (B, mem, want_batch, dt)}
+                      '(%.0f GB of host memory available; the GPU runs batch %d) -- %.1f s wall' % (B, mem, want_batch, dt)}
 
 
-CONV_FAMILY_INFER = ('conv family: conv_x3_kernel<*> (3x3 stride-1 layers, direct, fp32 products from six bf16 products on '
-                     'v_mfma_f32_32x32x16_bf16; decoder bilinear x2 fused) + conv_dma_kernel<*> (stride-2, dilated, 1x1, 16-wide: fp32 MFMA) '
-                     '+ conv_thin_kernel<*> (<= 16 output channels, fp32 MFMA); mfma_mode 0: conv_wino_kernel<*> (Winograd F(2x2,3x3), '
-                     'fp32 MFMA) instead of conv_x3')
-CONV_FAMILY_TRAIN = ('conv family: conv_x3_kernel<*> / conv_dma_kernel<*> / conv_thin_kernel<*> (forward + data gradients over '
-                     'materialised plain tensors; stride-2 data gradient = conv_dma_s2d_kernel) + wgrad_*_kernel<*> (weight gradient on '
-                     'the fp32 MFMA: Winograd F(3x3,2x2), LDS-DMA GEMMs)')
 SPLIT_DTYPE = 'f32 (3x3 stride-1 convs: bf16x3 split operands, six bf16 products per fp32 product, fp32 accumulate; rest: fp32 MFMA / VALU)'
 
 
@@ -173,6 +195,255 @@ def self_launch(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+# ---- roofline: per-kernel rows (vr_profile_report) -> classes, each against its own ceiling --------------------------------
+def classify(name):
+    for prefix, label, pipe in KERNEL_CLASSES:
+        if prefix in name:
+            return label, pipe
+    return None, None
+
+
+def roofline_from_rows(rows, pmc_name, conv_totals):
+    """rows: [(kernel name, calls, ms, algorithmic flops, algorithmic bytes, calls with figures)] of ONE profiled step."""
+    classes = {}
+    for name, calls, ms, flops, nbytes, noted in rows:
+        label, pipe = classify(name)
+        if label is None:
+            label, pipe = (('element-wise / thin / STFT kernels with algorithmic bytes (HBM streaming)', None) if noted and nbytes > 0
+                           else ('other: LSTM recurrence, BatchNorm finalize, weight-table refreshes, copies (latency / launch bound, no '
+                                 'algorithmic figure)', 'none'))
+        c = classes.setdefault(label, {'class': label, 'pipe': pipe, 'ms_per_step': 0.0, 'launches': 0, 'flops': 0.0, 'bytes': 0.0, 'kernels': []})
+        c['ms_per_step'] += ms; c['launches'] += calls; c['flops'] += flops; c['bytes'] += nbytes
+        c['kernels'].append(name.replace('vr::', ''))
+    out = []
+    for c in classes.values():
+        ms, pipe = c['ms_per_step'], c.pop('pipe')
+        mult = 6.0 if pipe == 'bf16' else 1.0                     # executed products per fp32 product on the bf16 pipe
+        pk = {'bf16': BF16_MFMA_PEAK_TFLOPS, 'fp32': FP32_MFMA_PEAK_TFLOPS}.get(pipe)
+        t_flop = (mult * c['flops'] / (pk * 1e12) * 1e3) if pk else 0.0          # ms at the matrix-pipe peak
+        t_byte = c['bytes'] / (HBM_PEAK_TBS * 1e12) * 1e3                         # ms at the HBM peak
+        if pipe == 'none' or ms <= 0 or (t_flop == 0 and t_byte == 0):
+            c.update({'bound': None, 'peak': None, 'achieved': None, 'unit': None, 'frac': None})
+        elif t_flop >= t_byte:
+            c.update({'bound': 'mfma', 'pipe': 'bf16 matrix pipe (v_mfma_f32_32x32x16_bf16), 6 executed products per fp32 product' if pipe == 'bf16'
+                      else 'fp32 matrix pipe (v_mfma_f32_32x32x2_f32 / 16x16x4)', 'peak': pk, 'unit': 'TFLOP/s',
+                      'achieved': mult * c['flops'] / (ms * 1e-3) / 1e12, 'frac': t_flop / ms})
+        else:
+            c.update({'bound': 'hbm', 'peak': HBM_PEAK_TBS * 1e3, 'unit': 'GB/s', 'achieved': c['bytes'] / (ms * 1e-3) / 1e9, 'frac': t_byte / ms})
+        c['algorithmic_gflop'] = c.pop('flops') / 1e9
+        c['algorithmic_mb'] = c.pop('bytes') / 1e6
+        out.append(c)
+    out.sort(key=lambda c: -c['ms_per_step'])
+    dom = next(c for c in out if c['bound'] is not None)
+    cms, cfl, cn, cby = conv_totals
+    traffic, src = None, None
+    path = os.path.join(ROOT, 'profiles', pmc_name)
+    if os.path.exists(path):        # rocprofv3 PMC passes of this same command (counters cannot be read in-process)
+        traffic = json.load(open(path)).get('bytes_per_launch')
+        src = 'profiles/' + pmc_name
+    total_ms = sum(c['ms_per_step'] for c in out)
+    return {'bound': dom['bound'], 'kernel': dom['class'], 'achieved': dom['achieved'], 'peak': dom['peak'], 'unit': dom['unit'],
+            'frac': dom['frac'], 'traffic': traffic,
+            'frac_note': 'the dominant class (largest share of the serialised kernel time: %.2f of %.2f ms) against ITS OWN ceiling; every '
+                         'class is in `classes`: frac = max(executed FLOPs / pipe peak, algorithmic bytes / 8 TB/s) / measured time'
+                         % (dom['ms_per_step'], total_ms),
+            'frac_fp32_equivalent': (cfl / (cms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS) if cms > 0 else None,
+            'frac_fp32_equivalent_note': 'rounds 1-3 figure: direct-convolution FLOPs of ALL conv launches / their summed time / %.1f TFLOP/s '
+                                         '(fp32 MFMA peak) -- not a ceiling for conv_x3, which runs on the bf16 pipe' % FP32_MFMA_PEAK_TFLOPS,
+            'classes': out,
+            'kernels': [[n.replace('vr::', ''), calls, round(ms, 4), round(fl / 1e9, 3), round(by / 1e6, 3)] for n, calls, ms, fl, by, _ in
+                        sorted(rows, key=lambda r: -r[2])],
+            'kernels_columns': ['kernel', 'launches', 'ms', 'algorithmic GFLOP', 'algorithmic MB'],
+            'source': 'the fastest of THREE EXTRA steps after the timed region, every launch serialised on one stream and bracketed by HIP events on '
+                      'the stream it is launched on (the timed steps overlap lanes and streams, so kernel_ms_per_step can exceed ms_per_step)',
+            'traffic_unit': 'HBM bytes per conv launch (mean over the conv launches of a step; rocprofv3 FETCH_SIZE x2 '
+                            'gfx950 correction + WRITE_SIZE, %s)' % src,
+            'algorithmic_bytes_per_launch': cby / max(cn, 1),
+            'algorithmic_bytes_note': 'input-sized tensor + output-sized tensor + weights, once each, for EVERY conv launch (forward, data '
+                                      'gradient, weight gradient); rounds 1-3 counted the forward launches only and divided by all launches',
+            'launches_per_step': sum(c['launches'] for c in out), 'conv_launches_per_step': cn, 'kernel_ms_per_step': total_ms,
+            'conv_kernel_ms_per_step': cms, 'algorithmic_gflop_per_step': cfl / 1e9}
+
+
+# ---- runtimes: the real one (HIP library + RCCL) and a stub that keeps ONLY the multi-rank control flow -----------------------
+class Runtime(object):
+    """World / rank / barrier / max-over-ranks timing shared by every workload.  backend 'nccl' = RCCL on the GPUs; 'gloo' + stub
+    workloads (VR_BENCH_STUB=1) run the same control flow on CPU for tests/test_bench_multirank.py."""
+
+    def __init__(self, args):
+        self.stub = bool(os.environ.get('VR_BENCH_STUB'))
+        self.world = int(os.environ.get('WORLD_SIZE', '1'))
+        self.rank = int(os.environ.get('RANK', '0'))
+        self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        if self.world != args.gpus and self.rank == 0:
+            print('bench.py: --gpus %d but the launcher started %d ranks; measuring %d' % (args.gpus, self.world, self.world), file=sys.stderr)
+        self.dist = None
+        if self.stub:
+            self.dev = torch.device('cpu')
+            if self.world > 1:
+                import torch.distributed as dist
+                self.dist = dist
+                dist.init_process_group('gloo')
+        else:
+            if self.world > 1:
+                import torch.distributed as dist
+                self.dist = dist
+                os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+                dist.init_process_group('nccl', device_id=torch.device('cuda', self.local_rank))
+            torch.cuda.set_device(self.local_rank)
+            self.dev = torch.device('cuda', self.local_rank)
+        self.per_rank = []
+
+    def sync(self):
+        if not self.stub:
+            torch.cuda.synchronize()
+
+    def barrier(self):
+        self.sync()
+        if self.world > 1:
+            self.dist.barrier()
+        self.sync()
+
+    def timed(self, step, steps, warmup):
+        """W untimed warm-up steps, then EXACTLY K steps between barriers; MAX over ranks."""
+        for _ in range(warmup):
+            step()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.barrier()
+        dt = time.perf_counter() - t0
+        self.per_rank = [dt]
+        if self.world > 1:
+            tt = torch.tensor([dt], device=self.dev, dtype=torch.float64)
+            every = [torch.zeros_like(tt) for _ in range(self.world)]
+            self.dist.all_gather(every, tt)
+            self.per_rank = [float(t.item()) for t in every]
+            dt = max(self.per_rank)
+        return dt
+
+    def max_over_ranks(self, value):
+        if self.world > 1:
+            tt = torch.tensor([value], device=self.dev, dtype=torch.float64)
+            self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+            value = float(tt.item())
+        return value
+
+    def finish(self):
+        if self.world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+class NativeWorkloads(object):
+    """The product: libvr_mi355.so through vocal_remover_amd."""
+
+    def __init__(self, rt, args):
+        self.rt, self.args = rt, args
+        if not os.path.exists(__graft_entry__.LIB):
+            __graft_entry__.build()
+        self.vr = __graft_entry__.load_package()
+        self.nat = self.vr.native
+        self.net, self.sd = seeded_state(self.vr)
+        self.net.to(rt.dev)
+        L = int(round(args.seconds * SR))
+        self.T = 1 + L // HOP
+        pl, pr, roi = self.vr.dataset.make_padding(self.T, CROP, 64)
+        self.crops_plain = (self.T + pl + pr - 128) // roi
+        self.crops_tta = self.crops_plain + (self.T + pl + pr + roi - 128) // roi
+        self.wave_host = synth_wave(args.seconds, rt.rank)
+        self.wave = torch.from_numpy(self.wave_host).to(rt.dev)
+        self.sp = self.vr.inference.Separator(self.net, rt.dev, batchsize=args.batchsize, cropsize=CROP)
+
+    def infer_step(self, tta, host=False):
+        self.net.eval()
+        wave = self.wave_host if host else self.wave
+        return lambda: self.sp.separate_wave(wave, tta=tta)
+
+    def set_mode(self, mfma_mode=None, bf16=None):
+        if bf16 is not None:
+            self.net.set_option('mfma_bf16', 1 if bf16 else 0)
+        if mfma_mode is not None:
+            self.net.set_option('mfma_mode', mfma_mode)
+
+    def trainer(self, wire):
+        from vocal_remover_amd import train as vtrain
+        rt = self.rt
+        tr = vtrain.Trainer(self.net, lr=1e-3, world_size=rt.world, rank=rt.rank, backend='rccl' if rt.world > 1 else 'none',
+                            wire=wire if rt.world > 1 else 'fp32')
+        g = torch.Generator().manual_seed(rt.rank)
+        B = self.args.train_batch
+        X = torch.rand((B, 2, N_FFT // 2 + 1, CROP), generator=g)
+        y = (X * torch.rand((B, 2, N_FFT // 2 + 1, CROP), generator=g)).to(rt.dev)
+        X = X.to(rt.dev)
+        return (lambda: tr.step(X, y)), tr.reduce, self.net.zero_grad
+
+    def end_train(self):
+        self.net.eval()
+
+    def profile(self, step):
+        """One step with every kernel launch timed (vr_profile_begin/end/report) -> (conv totals, per-kernel rows)."""
+        nat, h = self.nat, self.net._handle.h
+        nat.check(nat.lib().vr_profile_begin(h))
+        step()
+        cms, cfl, cn, cby = ctypes.c_double(), ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
+        nat.check(nat.lib().vr_profile_end(h, ctypes.byref(cms), ctypes.byref(cfl), ctypes.byref(cn), ctypes.byref(cby)))
+        need = nat.lib().vr_profile_report(h, None, 0)
+        buf = ctypes.create_string_buffer(int(need))
+        nat.lib().vr_profile_report(h, buf, need)
+        rows = []
+        for ln in buf.value.decode().splitlines():
+            name, calls, ms, fl, by, noted = ln.split('\t')
+            rows.append((name, int(calls), float(ms), float(fl), float(by), int(noted)))
+        return (cms.value, cfl.value, cn.value, cby.value), rows
+
+    def cpu_baseline(self, which):
+        return cpu_baseline_infer(self.sd) if which == 'infer' else cpu_baseline_train(self.sd, self.args.train_batch)
+
+
+class StubWorkloads(object):
+    """VR_BENCH_STUB=1: no GPU, no library -- sleeps stand for kernels, a gloo all-reduce of a bucket-sized CPU tensor for the gradient
+    exchange.  Exists so that bench.py's multi-rank control flow (self-launch, barriers, per-rank wall all-gather, all-reduce timing,
+    rank-0-only JSON line) runs under pytest at world 2 and 8 before the driver's first 8-GPU launch."""
+
+    def __init__(self, rt, args):
+        self.rt, self.args = rt, args
+        self.T, self.crops_plain, self.crops_tta = 1292, 11, 23
+        self.bucket = torch.zeros(1 << 16)
+
+    def infer_step(self, tta, host=False):
+        ms = (2.0 if tta else 1.0) * (1.0 + 0.25 * self.rt.rank)          # the slowest rank must set the job's time
+        return lambda: time.sleep(ms * 1e-3)
+
+    def set_mode(self, mfma_mode=None, bf16=None):
+        pass
+
+    def trainer(self, wire):
+        rt = self.rt
+
+        def reduce():
+            if rt.world > 1:
+                rt.dist.all_reduce(self.bucket, op=rt.dist.ReduceOp.SUM)
+
+        def step():
+            time.sleep(3e-3 * (1.0 + 0.25 * rt.rank))
+            reduce()
+        return step, reduce, (lambda: None)
+
+    def end_train(self):
+        pass
+
+    def profile(self, step):
+        step()
+        rows = [('vr::conv_x3_kernel<64, 8>', 10, 0.5, 1e11, 1e8, 10), ('vr::conv_dma_kernel<1, 1, 1, 1, 32, 8, 16, 32, false>', 4, 0.1, 1e9, 5e7, 4),
+                ('vr::upsample2x_rows_kernel', 3, 0.05, 0.0, 2e7, 3), ('vr::bilstm_reg_kernel<64>', 2, 0.1, 0.0, 0.0, 0)]
+        return (0.6, 1.01e11, 14, 1.5e8), rows
+
+    def cpu_baseline(self, which):
+        return {'value': 1.0, 'unit': 'spectrogram-frames/sec', 'cores': 1, 'kind': 'port', 'sample': 'stub'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -184,7 +455,7 @@ def main():
     ap.add_argument('--batchsize', type=int, default=0, help='crops per device batch (0 = all crops of a pass)')
     ap.add_argument('--train-batch', type=int, default=16)
     ap.add_argument('--wire', choices=['fp32', 'bf16'], default='fp32', help='gradient bucket format on xGMI (N > 1)')
-    ap.add_argument('--bf16', action='store_true', help='--mode train: configs[4] arithmetic (bf16 MFMA operands, bf16 bucket)')
+    ap.add_argument('--bf16', action='store_true', help='--mode train: bf16 MFMA operands + bf16 bucket (an experiment, not configs[4])')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
     if args.tta:
@@ -195,138 +466,53 @@ def main():
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         self_launch(args)
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and rank == 0:
-        print('bench.py: --gpus %d but the launcher started %d ranks; measuring %d' % (args.gpus, world, world), file=sys.stderr)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    rt = Runtime(args)
+    wl = (StubWorkloads if rt.stub else NativeWorkloads)(rt, args)
+    world, rank, T = rt.world, rt.rank, wl.T
+    pmc = lambda which: '%s_%s_pmc.json' % (PROFILE_ROUND, which)        # noqa: E731
 
-    if not os.path.exists(__graft_entry__.LIB):
-        __graft_entry__.build()
-    vr = __graft_entry__.load_package()
-    nat = vr.native
-    net, sd = seeded_state(vr)
-    net.to(dev)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def timed(step, steps, warmup):
-        """W untimed warm-up steps, then EXACTLY K steps between barriers; MAX over ranks."""
-        for _ in range(warmup):
-            step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        barrier()
-        dt = time.perf_counter() - t0
-        timed.per_rank = [dt]
-        if world > 1:
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-            every = [torch.zeros_like(tt) for _ in range(world)]
-            dist.all_gather(every, tt)
-            timed.per_rank = [float(t.item()) for t in every]
-            dt = max(timed.per_rank)
-        return dt
-    timed.per_rank = []
-
-    def conv_profile(step):
-        """HIP events (on the library's stream) around every MFMA-conv launch of one step, kernels serialised."""
-        nat.check(nat.lib().vr_profile_begin(net._handle.h))
-        step()
-        cms, cfl, cn, cby = ctypes.c_double(), ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
-        nat.check(nat.lib().vr_profile_end(net._handle.h, ctypes.byref(cms), ctypes.byref(cfl), ctypes.byref(cn), ctypes.byref(cby)))
-        return cms.value, cfl.value, cn.value, cby.value
-
-    def roofline(step, kernel, pmc_name):
+    def roofline(step, pmc_name):
         # three profiled steps, the fastest one is reported: a single serialised step is exposed to one-off stalls (seen once: a tta
         # step at 2x its usual kernel time while the timed steps of the same run were normal)
-        cms, cfl, cn, cby = min((conv_profile(step) for _ in range(3)), key=lambda r: r[0])
-        achieved = cfl / (cms * 1e-3) / 1e12 if cms > 0 else 0.0
-        traffic, src = None, None
-        path = os.path.join(ROOT, 'profiles', pmc_name)
-        if os.path.exists(path):        # rocprofv3 PMC passes of this same command (counters cannot be read in-process)
-            traffic = json.load(open(path)).get('bytes_per_launch')
-            src = 'profiles/' + pmc_name
-        return {'bound': 'mfma', 'kernel': kernel, 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
-                'source': 'the fastest of THREE EXTRA steps after the timed region, every launch serialised on one stream and bracketed by HIP events on '
-                          'the library\'s stream (the timed steps overlap 2 lanes x 2 streams, so kernel_ms_per_step can exceed ms_per_step)',
-                'peak_note': 'peak = fp32 MFMA (v_mfma_f32_32x32x2_f32 = the fp32 vector rate).  In mfma_mode 2 the 3x3 stride-1 convs run '
-                             'on the bf16 pipe instead: 2500 TFLOP/s dense / 6 products = %.0f fp32-equivalent TFLOP/s at 2.4 GHz -- the '
-                             'chip clocks down to ~1.7 GHz under that load (profiles/README.md); their MFMA-pipe busy fraction is in '
-                             'profiles/r03_infer_sq_pmc.md' % (2500.0 / 6.0),
-                'traffic_unit': 'HBM bytes per launch (mean over the conv launches of a step; rocprofv3 FETCH_SIZE x2 '
-                                'gfx950 correction + WRITE_SIZE, %s)' % src,
-                'algorithmic_bytes_per_launch': cby / max(cn, 1),
-                'achieved_note': 'algorithmic FLOPs = 2 x multiply-adds of the direct convolutions / summed launch '
-                                 'durations (HIP events); the Winograd launches execute 2.25x fewer',
-                'launches_per_step': cn, 'kernel_ms_per_step': cms, 'algorithmic_gflop_per_step': cfl / 1e9}
-
-    L = int(round(args.seconds * SR))
-    T = 1 + L // HOP
-    pl, pr, roi = vr.dataset.make_padding(T, CROP, 64)
-    crops_plain = (T + pl + pr - 128) // roi
-    crops_tta = crops_plain + (T + pl + pr + roi - 128) // roi
-    wave_host = synth_wave(args.seconds, rank)
-    wave = torch.from_numpy(wave_host).to(dev)
-    sp = vr.inference.Separator(net, dev, batchsize=args.batchsize, cropsize=CROP)
+        conv_totals, rows = min((wl.profile(step) for _ in range(3)), key=lambda r: sum(x[2] for x in r[1]))
+        return roofline_from_rows(rows, pmc_name, conv_totals)
 
     def run_infer(tta):
-        net.eval()
-        step = lambda: sp.separate_wave(wave, tta=tta)                     # noqa: E731
-        dt = timed(step, args.steps, args.warmup)
-        crops = crops_tta if tta else crops_plain
+        step = wl.infer_step(tta)
+        dt = rt.timed(step, args.steps, args.warmup)
+        crops = wl.crops_tta if tta else wl.crops_plain
         res = {'frames_per_sec': world * T * args.steps / dt, 'ms_per_step': dt / args.steps * 1e3,
                'computed_frames_per_sec': world * crops * CROP * args.steps / dt, 'crops_per_step_per_gpu': crops,
-               'frames_per_step_per_gpu': T, 'ms_per_step_per_rank': [t / args.steps * 1e3 for t in timed.per_rank]}
+               'frames_per_step_per_gpu': T, 'ms_per_step_per_rank': [t / args.steps * 1e3 for t in rt.per_rank]}
         return res, step
 
-    def run_train(bf16=False):
-        from vocal_remover_amd import train as vtrain
-        net.set_option('mfma_bf16', 1 if bf16 else 0)
+    def run_train(bf16=False, mfma_mode=None):
+        wl.set_mode(bf16=bf16)
+        if mfma_mode is not None:
+            wl.set_mode(mfma_mode=mfma_mode)
         wire = 'bf16' if (bf16 and world > 1) else args.wire
-        trainer = vtrain.Trainer(net, lr=1e-3, world_size=world, rank=rank, backend='rccl' if world > 1 else 'none',
-                                 wire=wire if world > 1 else 'fp32')
-        g = torch.Generator().manual_seed(rank)
+        step, reduce, zero_grad = wl.trainer(wire)
         B = args.train_batch
-        X = torch.rand((B, 2, N_FFT // 2 + 1, CROP), generator=g)
-        y = (X * torch.rand((B, 2, N_FFT // 2 + 1, CROP), generator=g)).to(dev)
-        X = X.to(dev)
-        step = lambda: trainer.step(X, y)                                   # noqa: E731
-        dt = timed(step, args.steps, args.warmup)
-        per_rank = [t / args.steps * 1e3 for t in timed.per_rank]
+        dt = rt.timed(step, args.steps, args.warmup)
+        per_rank = [t / args.steps * 1e3 for t in rt.per_rank]
         allreduce_ms = None
         if world > 1:
             # the exchange alone, outside the timed region: the gradient bucket of the last step, summed three more times with a
             # device sync on both sides (vr_allreduce_grads runs on the library's own stream)
             ts = []
             for _ in range(3):
-                barrier()
+                rt.barrier()
                 t0 = time.perf_counter()
-                trainer.reduce()
-                torch.cuda.synchronize()          # device-wide: also the library's own (non-blocking) stream
+                reduce()
+                rt.sync()                         # device-wide: also the library's own (non-blocking) stream
                 ts.append((time.perf_counter() - t0) * 1e3)
-            tt = torch.tensor([min(ts)], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            allreduce_ms = float(tt.item())
-            net.zero_grad()
+            allreduce_ms = rt.max_over_ranks(min(ts))
+            zero_grad()
         res = {'frames_per_sec': world * B * CROP * args.steps / dt, 'ms_per_step': dt / args.steps * 1e3,
                'ms_per_step_per_rank': per_rank, 'allreduce_ms': allreduce_ms,
                'global_batch': world * B, 'frames_per_step_per_gpu': B * CROP,
-               'workload': 'configs[%d]: train.py step, batch %d x [2,1025,256] per GPU, fwd + L1 + bwd%s + Adam; '
-                           'Dropout2d live (library RNG)' % (4 if bf16 else 3, B, ' + RCCL all-reduce (%s bucket)' % wire if world > 1 else ''),
+               'workload': 'configs[3]: train.py step, batch %d x [2,1025,256] per GPU, fwd + L1 + bwd%s + Adam; '
+                           'Dropout2d live (library RNG)' % (B, ' + RCCL all-reduce (%s bucket)' % wire if world > 1 else ''),
                'dtype': 'bf16 MFMA operands (Winograd forward / data-gradient / weight-gradient convs, 1x1 weight-gradient GEMM), '
                         'fp32 accumulation, storage, master weights and Adam; remaining convs fp32' if bf16 else SPLIT_DTYPE,
                'parallelism': 'dp%d (one RCCL all-reduce of the flat 14.74 M-element gradient bucket per step)' % world}
@@ -342,12 +528,12 @@ def main():
             if args.seconds == 30.0 else '%.0f s synthetic song, %d crops' % (args.seconds, res['crops_per_step_per_gpu'])
         metric = 'spectrogram-frames/sec (inference, CascadedNet n_fft=2048)'
         parallelism = 'replicas x%d (songs shard, no collective)' % world
-        roof = roofline(step, CONV_FAMILY_INFER, 'r03_infer_pmc.json' if primary_mode == 'infer' else 'r03_tta_pmc.json')
+        roof = roofline(step, pmc(primary_mode))
     else:
         res, step = run_train(args.bf16)
         workload, metric, parallelism = res['workload'], 'spectrogram-frames/sec (train-step, CascadedNet n_fft=2048)', res['parallelism']
-        roof = roofline(step, CONV_FAMILY_TRAIN, 'r03_train_pmc.json')
-        net.eval()
+        roof = roofline(step, pmc('train'))
+        wl.end_train()
     if rank == 0:
         out = {
             'metric': metric, 'value': res['frames_per_sec'], 'unit': 'spectrogram-frames/sec',
@@ -367,35 +553,21 @@ def main():
     if args.mode == 'all':
         # PCIe-inclusive rate of the headline workload: host numpy in, host numpy out (2 x 10.6 MB + 2 x 10.6 MB per step)
         if world == 1:
-            net.eval()
-            dt = timed(lambda: sp.separate_wave(wave_host, tta=False), max(3, args.steps // 2), 1)
+            dt = rt.timed(wl.infer_step(False, host=True), max(3, args.steps // 2), 1)
             extra['pcie_inclusive_frames_per_sec'] = T * max(3, args.steps // 2) / dt
         tta_res, tta_step = run_infer(True)
-        tta_roof = roofline(tta_step, CONV_FAMILY_INFER, 'r03_tta_pmc.json')
+        tta_roof = roofline(tta_step, pmc('tta'))
         train_res, train_step_fn = run_train()
-        train_roof = roofline(train_step_fn, CONV_FAMILY_TRAIN, 'r03_train_pmc.json')
-        bf_res, _ = run_train(True)
-        net.set_option('mfma_bf16', 0)
+        train_roof = roofline(train_step_fn, pmc('train'))
         # the same workloads with v_mfma_f32_32x32x2_f32 everywhere (mfma_mode 0: Winograd F(2x2,3x3) on the fp32 matrix pipe for the
         # 3x3 stride-1 layers, materialised decoder upsample) -- the round-1/2 arithmetic, beside the default above
-        net.set_option('mfma_mode', 0)
+        wl.set_mode(mfma_mode=0)
         f32_inf, _ = run_infer(False)
-        net.set_option('mfma_mode', 0)          # (run_train returns to the default mode through 'mfma_bf16')
-        f32_trn = None
         try:
-            from vocal_remover_amd import train as vtrain
-            trainer = vtrain.Trainer(net, lr=1e-3, world_size=world, rank=rank, backend='rccl' if world > 1 else 'none',
-                                     wire=args.wire if world > 1 else 'fp32')
-            g = torch.Generator().manual_seed(rank)
-            B = args.train_batch
-            Xs = torch.rand((B, 2, N_FFT // 2 + 1, CROP), generator=g)
-            ys = (Xs * torch.rand((B, 2, N_FFT // 2 + 1, CROP), generator=g)).to(dev)
-            Xs = Xs.to(dev)
-            dts = timed(lambda: trainer.step(Xs, ys), args.steps, args.warmup)
-            f32_trn = {'frames_per_sec': world * B * CROP * args.steps / dts, 'ms_per_step': dts / args.steps * 1e3}
+            f32_trn, _ = run_train(False, mfma_mode=0)
         finally:
-            net.set_option('mfma_mode', -1)
-        net.eval()
+            wl.set_mode(mfma_mode=-1)
+        wl.end_train()
         if rank == 0:
             out['config']['pcie_inclusive_frames_per_sec'] = extra.get('pcie_inclusive_frames_per_sec')
             out['tta'] = {'metric': 'spectrogram-frames/sec (inference --tta, configs[2])', 'value': tta_res['frames_per_sec'],
@@ -407,11 +579,6 @@ def main():
                             'global_batch': train_res['global_batch'], 'workload': train_res['workload'],
                             'parallelism': train_res['parallelism'], 'dtype': SPLIT_DTYPE, 'roofline': train_roof,
                             'ms_per_step_per_rank': train_res['ms_per_step_per_rank'], 'allreduce_ms': train_res['allreduce_ms']}
-            out['train_bf16'] = {'metric': 'spectrogram-frames/sec (train-step with bf16 MFMA OPERANDS on fp32 storage, %d GPU%s -- NOT configs[4] '
-                                           'itself: no bf16 activation storage%s)' % (world, 's' if world > 1 else '', '' if world > 1 else ', no data parallelism'),
-                                 'value': bf_res['frames_per_sec'], 'ms_per_step': bf_res['ms_per_step'], 'steps': args.steps,
-                                 'warmup': args.warmup, 'global_batch': bf_res['global_batch'], 'workload': bf_res['workload'],
-                                 'parallelism': bf_res['parallelism'], 'dtype': bf_res['dtype']}
             out['fp32_mfma'] = {
                 'what': "vr_set_option('mfma_mode', 0): every convolution on v_mfma_f32_32x32x2_f32 / 16x16x4 (fp32 operands; Winograd "
                         'F(2x2,3x3) for the 3x3 stride-1 layers, decoder upsample materialised) -- the default (mode 2) instead forms the '
@@ -419,20 +586,15 @@ def main():
                         'tests at the same tolerances (tests/test_gpu_parity.py, test_gpu_configs.py, test_gpu_b16.py)',
                 'dtype': 'f32',
                 'infer': {'value': f32_inf['frames_per_sec'], 'ms_per_step': f32_inf['ms_per_step']},
-                'train': {'value': f32_trn['frames_per_sec'], 'ms_per_step': f32_trn['ms_per_step']} if f32_trn else None}
+                'train': {'value': f32_trn['frames_per_sec'], 'ms_per_step': f32_trn['ms_per_step']}}
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            if primary_mode in ('infer', 'tta'):
-                out['cpu_baseline'] = cpu_baseline_infer(sd)
-            else:
-                out['cpu_baseline'] = cpu_baseline_train(sd, args.train_batch)
+            out['cpu_baseline'] = wl.cpu_baseline('infer' if primary_mode in ('infer', 'tta') else 'train')
             if args.mode == 'all':
-                out['train']['cpu_baseline'] = cpu_baseline_train(sd, args.train_batch)
+                out['train']['cpu_baseline'] = wl.cpu_baseline('train')
         print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    rt.finish()
 
 
 if __name__ == '__main__':

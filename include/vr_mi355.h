@@ -198,11 +198,20 @@ int vr_resample(int device, const float* x, int channels, int64_t n_in, int sr_i
 int vr_xcorr_argmax(int device, const float* a, int64_t na, const float* b, int64_t nb, int64_t* argmax_out);
 
 /* ---- measurement hooks (bench.py) ----------------------------------------------------------- */
-/* Bracket subsequent calls: every MFMA-conv launch is timed with HIP events on the handle's stream.
+/* Bracket subsequent calls: every kernel launch is timed with HIP events on the stream it is launched on (the executor runs
+ * every kernel on ONE stream while profiling); conv_* aggregate the convolution launches.
  * conv_flops = 2 x multiply-adds of the direct convolutions (the Winograd kernel performs fewer),
  * conv_bytes = algorithmic HBM bytes (virtual input + weights + output of each launch, once each). */
 int vr_profile_begin(vr_handle h);
 int vr_profile_end(vr_handle h, double* conv_ms, double* conv_flops, int* conv_launches, double* conv_bytes);
+/* Per-kernel totals of the step bracketed by the last vr_profile_begin / vr_profile_end: EVERY kernel the library launched
+ * (HIP events on the stream each launch went to), one text line per kernel name
+ *     name \t calls \t milliseconds \t algorithmic FLOPs \t algorithmic HBM bytes \t calls that carried figures \n
+ * (FLOPs / bytes: convolutions = 2 x multiply-adds of the direct form and input + output + weights once each -- forward,
+ * data-gradient and weight-gradient launches alike; element-wise kernels = bytes read + written once; 0 where a kernel has no
+ * noted figure).  Returns the size needed incl. the terminator; copies at most `capacity` bytes.  bench.py builds
+ * `roofline.classes` from it. */
+int64_t vr_profile_report(vr_handle h, char* buf, int64_t capacity);
 
 /* ---- test hooks (tests/ only) ---------------------------------------------------------------- */
 /* One convolution through the library's conv dispatcher: x [N,Cin,H,W], w OIHW, padding = dilation

@@ -93,28 +93,42 @@ def test_reference_train_epoch_statements_run_through_the_autograd_shim(vr):
     assert any(float(v.abs().max()) > 0 for v in b.grads(keys={'stg3_full_band_net.dec1.conv1.conv.0.weight'}).values())
 
 
-def test_flat_parameter_is_detached_when_the_handle_goes_away(vr):
-    """the flat Parameter / .grad are zero-copy views of the native arenas.  Moving the model off the GPU (or to another
-    one) closes the handle: optimizers built before must neither touch freed memory nor silently stop updating the new handle."""
+def test_flat_parameter_follows_the_model_across_devices(vr):
+    """ADVICE r2 + r3: the flat Parameter / .grad are zero-copy views of the native arenas.  Moving the model off the GPU closes the
+    handle: an optimizer built before must not touch freed memory (the Parameter is emptied, with a warning), and -- like
+    nn.Module.to, which keeps Parameter objects valid for existing optimizers -- the SAME Parameter is rebound to the next handle's
+    arenas, so a torch optimizer built before the move keeps updating the model.  The native Adam's moments live in the closed
+    handle: it raises instead of silently restarting."""
     from vocal_remover_amd import train as vtrain
     m, sd = _model(vr)
     m.train(); m.set_dropout_masks(None)
     old = m.parameters()[0]
-    torch_opt = torch.optim.Adam([old], lr=1e-3)
+    torch_opt = torch.optim.SGD([old], lr=1e-3)            # (stateless: torch's own optimizer state would not move with .to())
     native_opt = vtrain.Adam(m.parameters(), lr=1e-3)
     X, y = train_step.synth_batch(2, T=64, n_fft=N_FFT, seed=3)
     m.train_step(X.to(DEV), y.to(DEV), 1)
     assert old.numel() > 1000 and old.grad is not None and float(old.grad.abs().max()) > 0
-    m.to('cpu')
+    with pytest.warns(UserWarning, match='empty until the model moves back'):
+        m.to('cpu')
     assert old.numel() == 0 and old.grad is None          # detached: nothing left that points into the freed arenas
-    torch_opt.step()                                       # a stale torch optimizer steps an empty tensor: harmless
+    torch_opt.step()                                       # steps an empty tensor meanwhile: harmless
     m.to(torch.device(DEV))
     new = m.parameters()[0]
-    assert new is not old and new.numel() > 1000 and new.data_ptr() != 0
+    assert new is old and new.numel() > 1000 and new.data_ptr() != 0      # the same object, rebound to the new arenas
     with pytest.raises(RuntimeError):
         native_opt.step()                                  # its moments lived in the closed handle
-    # the new handle trains with a fresh optimizer
+    # the optimizer built BEFORE the move still trains the model
     m.train(); m.set_dropout_masks(None)
+    m.zero_grad()
+    before = m.state_dict()['out.weight'].clone()
+    m.train_step(X.to(DEV), y.to(DEV), 1)
+    assert old.grad is not None and float(old.grad.abs().max()) > 0
+    torch_opt.step()
+    torch.cuda.synchronize()
+    m.set_option('params_dirty', 1)
+    m._host_stale = True
+    assert not torch.equal(m.state_dict()['out.weight'], before)
+    # and a fresh native optimizer works on the new handle
     opt = vtrain.Adam(m.parameters(), lr=1e-3)
     before = m.state_dict()['out.weight'].clone()
     m.train_step(X.to(DEV), y.to(DEV), 1)

@@ -344,6 +344,17 @@ int vr_profile_end(vr_handle h, double* conv_ms, double* conv_flops, int* conv_l
     return guard([&] { h->m.profile_end(conv_ms, conv_flops, conv_bytes, conv_launches); });
 }
 
+int64_t vr_profile_report(vr_handle h, char* buf, int64_t capacity) {
+    if (!h) { g_err = "null handle"; return VR_ERR_BAD_ARGUMENT; }
+    const std::string& r = h->m.profile_report;
+    if (buf && capacity > 0) {
+        const size_t n = std::min<size_t>(r.size(), (size_t)capacity - 1);
+        std::memcpy(buf, r.data(), n);
+        buf[n] = 0;
+    }
+    return (int64_t)r.size() + 1;
+}
+
 int vr_debug_conv2d(vr_handle h, const float* x, int N, int Cin, int H, int W, const float* w, int Cout, int ksize,
                     int stride, int dil_h, int dil_w, int upsample, const float* affine, float slope, const float* bias,
                     float* out, float* stats_out) {

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void augment_kernel(const float2* __restrict__
 void launch_augment(const float2* X, const float2* Y, const float2* Xi, const float2* Yi, const AugDesc* desc, const float* rw,
                     int B, int T, int bins, float* Xmag, float* Ymag, hipStream_t st) {
     const dim3 grid((T + 31) / 32, (bins + 31) / 32, B * 2), block(32, 8);
-    hipLaunchKernelGGL(augment_kernel, grid, block, 0, st, X, Y, Xi, Yi, desc, rw, T, bins, Xmag, Ymag);
+    VR_LAUNCH(augment_kernel, grid, block, 0, st, X, Y, Xi, Yi, desc, rw, T, bins, Xmag, Ymag);
     VR_HIP(hipGetLastError());
 }
 

@@ -157,18 +157,21 @@ int bn_bwd_chunks(const BnBwdArgs& a) {
 }
 
 void launch_bn_bwd(const BnBwdArgs& a, hipStream_t st) {
+    const double elems = (double)a.N * a.C * a.H * a.W;
     if (a.coef) {
         const int nch = bn_bwd_chunks(a);
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nch, a.C), dim3(256), 0, st, a);
+        prof_note(0.0, 8.0 * elems);                         // reads z and g
+        VR_LAUNCH(bn_bwd_reduce_kernel, dim3(nch, a.C), dim3(256), 0, st, a);
         VR_HIP(hipGetLastError());
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(a.C), dim3(256), 0, st, a, nch);
+        VR_LAUNCH(bn_bwd_finalize_kernel, dim3(a.C), dim3(256), 0, st, a, nch);
         VR_HIP(hipGetLastError());
     }
     const long long total = (long long)a.N * a.C * a.H * a.W;
     const bool vec = (a.W & 3) == 0 && (a.sH & 3) == 0 && (a.sC & 3) == 0 && (a.sN & 3) == 0 &&
                      ((reinterpret_cast<uintptr_t>(a.z) | reinterpret_cast<uintptr_t>(a.g)) & 15) == 0;
-    if (vec) hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+    prof_note(0.0, 12.0 * elems);                            // reads z and g, writes g
+    if (vec) VR_LAUNCH(bn_bwd_apply4_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, a);
+    else VR_LAUNCH(bn_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
     VR_HIP(hipGetLastError());
 }
 
@@ -315,17 +318,18 @@ void launch_upsample_bwd(const float* dhi, int N, int C, int H, int W, float* gl
     const long long total = (long long)N * C * H * W;
     const float rh = (float)(H - 1) / (float)(2 * H - 1), rw = (float)(W - 1) / (float)(2 * W - 1);
     static const bool tiled = !getenv("VR_NO_UPBWD_TILED");
+    prof_note(0.0, 4.0 * 6.0 * (double)total);               // reads the 4x larger gradient, read-modify-writes the low-resolution one
     if (tiled && W >= 16 && H >= 4) {
         const int tiles_w = (W + 31) / 32, tiles_h = (H + 7) / 8;
         const long long blocks = (long long)N * C * tiles_h * tiles_w;
         if (blocks < 0x7FFFFFFFLL) {
-            hipLaunchKernelGGL(upsample_bwd_tiled_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dhi, C, H, W, rh, rw, tiles_w,
+            VR_LAUNCH(upsample_bwd_tiled_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dhi, C, H, W, rh, rw, tiles_w,
                                tiles_h * tiles_w, glo, gN, gC, gH);
             VR_HIP(hipGetLastError());
             return;
         }
     }
-    hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dhi, N, C, H, W, rh, rw,
+    VR_LAUNCH(upsample_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dhi, N, C, H, W, rh, rw,
                        glo, gN, gC, gH);
     VR_HIP(hipGetLastError());
 }
@@ -344,7 +348,7 @@ __global__ void sum_h_kernel(const float* __restrict__ d, int N, int C, int H, i
 }
 void launch_sum_h(const float* d, int N, int C, int H, int W, float* out, hipStream_t st) {
     const int total = N * C * W;
-    hipLaunchKernelGGL(sum_h_kernel, dim3((total + 255) / 256), dim3(256), 0, st, d, N, C, H, W, out);
+    VR_LAUNCH(sum_h_kernel, dim3((total + 255) / 256), dim3(256), 0, st, d, N, C, H, W, out);
     VR_HIP(hipGetLastError());
 }
 
@@ -364,7 +368,7 @@ __global__ void avgpool_bwd_kernel(const float* __restrict__ gp, float* __restri
 void launch_avgpool_bwd(const float* gp, float* g, int N, int C, int H, int W, long long sN, long long sC, long long sH,
                         hipStream_t st) {
     const long long total = (long long)N * C * H * W;
-    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gp, g, N, C, H, W, sN,
+    VR_LAUNCH(avgpool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gp, g, N, C, H, W, sN,
                        sC, sH);
     VR_HIP(hipGetLastError());
 }
@@ -465,15 +469,17 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
 }
 void launch_reduce_rows(const float* part, long long stride, int P, float* out, long long n, int accumulate, float scale,
                         hipStream_t st) {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)n), dim3(256), 0, st, part, stride, P, out, n, accumulate, scale);
+    VR_LAUNCH(reduce_rows_kernel, dim3((unsigned)n), dim3(256), 0, st, part, stride, P, out, n, accumulate, scale);
     VR_HIP(hipGetLastError());
 }
 
 void launch_thin_dgrad(const Tensor& x, int CO, const float* w, const float* dz, float* g, int accumulate, hipStream_t st) {
     const long long total = (long long)x.N * x.C * x.H * x.W;
     const unsigned grid = (unsigned)((total + 255) / 256);
-    if (CO == 1) hipLaunchKernelGGL((thin_dgrad_kernel<1>), dim3(grid), dim3(256), 0, st, x, w, dz, g, accumulate);
-    else hipLaunchKernelGGL((thin_dgrad_kernel<2>), dim3(grid), dim3(256), 0, st, x, w, dz, g, accumulate);
+    // reads x (activation derivative), dz; writes (accumulating: read-modify-writes) g
+    prof_note(2.0 * CO * (double)total, 4.0 * ((accumulate ? 3.0 : 2.0) * (double)total + (double)CO * x.N * x.H * x.W));
+    if (CO == 1) VR_LAUNCH((thin_dgrad_kernel<1>), dim3(grid), dim3(256), 0, st, x, w, dz, g, accumulate);
+    else VR_LAUNCH((thin_dgrad_kernel<2>), dim3(grid), dim3(256), 0, st, x, w, dz, g, accumulate);
     VR_HIP(hipGetLastError());
 }
 
@@ -487,8 +493,9 @@ int thin_wgrad_blocks(const Tensor& x) {
 void launch_thin_wgrad(const Tensor& x, int CO, const float* dz, float* part, float* dw, int accumulate, hipStream_t st) {
     const int nb = thin_wgrad_blocks(x);
     const dim3 grid(nb, (x.C + 7) / 8);
-    if (CO == 1) hipLaunchKernelGGL((thin_wgrad_kernel<1>), grid, dim3(256), 0, st, x, dz, part);
-    else hipLaunchKernelGGL((thin_wgrad_kernel<2>), grid, dim3(256), 0, st, x, dz, part);
+    prof_note(2.0 * CO * (double)x.N * x.C * x.H * x.W, 4.0 * ((double)x.N * x.C * x.H * x.W + (double)CO * x.N * x.H * x.W));
+    if (CO == 1) VR_LAUNCH((thin_wgrad_kernel<1>), grid, dim3(256), 0, st, x, dz, part);
+    else VR_LAUNCH((thin_wgrad_kernel<2>), grid, dim3(256), 0, st, x, dz, part);
     VR_HIP(hipGetLastError());
     launch_reduce_rows(part, (long long)CO * x.C, nb, dw, (long long)CO * x.C, accumulate, 1.f, st);
 }
@@ -566,7 +573,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 }
 void launch_head_bwd(const float* dmask, const float* mask, int N, int H, int W, int bins, float* dlogit, hipStream_t st) {
     const long long total = (long long)N * 2 * H * W;
-    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dmask, mask, N, H, W, bins, dlogit);
+    VR_LAUNCH(head_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dmask, mask, N, H, W, bins, dlogit);
     VR_HIP(hipGetLastError());
 }
 
@@ -575,7 +582,9 @@ int head_loss_blocks(const Tensor& x) { return (int)(((long long)x.N * x.H * x.W
 void launch_head_loss(const Tensor& x, const float* w, const float* X, const float* Y, int bins, float gscale,
                       float* dlogit, float* mask_out, float* loss_part, float* loss_out, float loss_scale, hipStream_t st) {
     const int nb = head_loss_blocks(x);
-    hipLaunchKernelGGL(head_loss_kernel, dim3(nb), dim3(256), 0, st, x, w, X, Y, bins, gscale, dlogit, mask_out, loss_part);
+    // reads the C-channel feature map, X, Y; writes the 2-channel logit gradient (+ the mask when asked)
+    prof_note(4.0 * x.C * (double)x.N * x.H * x.W, 4.0 * ((double)x.N * x.C * x.H * x.W + (mask_out ? 8.0 : 6.0) * x.N * x.H * x.W));
+    VR_LAUNCH(head_loss_kernel, dim3(nb), dim3(256), 0, st, x, w, X, Y, bins, gscale, dlogit, mask_out, loss_part);
     VR_HIP(hipGetLastError());
     launch_reduce_rows(loss_part, 1, nb, loss_out, 1, 0, loss_scale, st);
 }
@@ -617,13 +626,13 @@ __global__ void s2_class_weights_kernel(const float* __restrict__ w, float* __re
 
 void launch_s2_class_weights(const float* w, float* wc, int Cin, int Cout, int CoutPad, int CinPad, hipStream_t st) {
     const long long n = 4LL * Cout * 9 * CinPad;
-    hipLaunchKernelGGL(s2_class_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, wc, Cin, Cout, CoutPad,
+    VR_LAUNCH(s2_class_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, wc, Cin, Cout, CoutPad,
                        CinPad);
     VR_HIP(hipGetLastError());
 }
 
 void launch_flip_transpose(const FlipDesc* d_descs, int n, hipStream_t st) {
-    hipLaunchKernelGGL(flip_transpose_kernel, dim3(64, n), dim3(256), 0, st, d_descs);
+    VR_LAUNCH(flip_transpose_kernel, dim3(64, n), dim3(256), 0, st, d_descs);
     VR_HIP(hipGetLastError());
 }
 
@@ -647,7 +656,8 @@ void launch_adam(float* p, const float* g, float* m, float* v, long long n, doub
     // scalars in double, as torch's python floats are (torch/optim/adam.py _single_tensor_adam)
     const double bc1 = 1.0 - std::pow(b1, (double)step);
     const double bc2s = std::sqrt(1.0 - std::pow(b2, (double)step));
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n, (float)b1, (float)b2,
+    prof_note(0.0, 28.0 * (double)n);                        // p, g, m, v read; p, m, v written
+    VR_LAUNCH(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n, (float)b1, (float)b2,
                        (float)(1.0 - b1), (float)(1.0 - b2), (float)(lr / bc1), (float)bc2s, (float)eps, (float)gscale);
     VR_HIP(hipGetLastError());
 }
@@ -666,11 +676,11 @@ __global__ void bf16_to_f32_kernel(const unsigned short* __restrict__ x, float* 
     y[i] = __uint_as_float((unsigned)x[i] << 16);
 }
 void launch_f32_to_bf16(const float* x, unsigned short* y, long long n, hipStream_t st) {
-    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n);
+    VR_LAUNCH(f32_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n);
     VR_HIP(hipGetLastError());
 }
 void launch_bf16_to_f32(const unsigned short* x, float* y, long long n, hipStream_t st) {
-    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n);
+    VR_LAUNCH(bf16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n);
     VR_HIP(hipGetLastError());
 }
 
@@ -691,7 +701,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
     }
 }
 void launch_channel_sum(const float* d, int N, int C, int W, float* out, int accumulate, hipStream_t st) {
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, st, d, N, C, W, out, accumulate);
+    VR_LAUNCH(channel_sum_kernel, dim3(C), dim3(256), 0, st, d, N, C, W, out, accumulate);
     VR_HIP(hipGetLastError());
 }
 

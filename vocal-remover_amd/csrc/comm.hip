@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -36,12 +37,21 @@ RcclApi& rccl() {
     static std::once_flag once;
     std::call_once(once, [] {
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* n : names) {          // 1. whatever RCCL this process already mapped (torch's)
-            api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
-            if (api.lib) break;
+        const char* forced = getenv("VR_RCCL_LIB");      // this library and nothing else (deployments with several RCCLs; the tests'
+        if (forced && *forced) {                         // "no RCCL on this machine" case)
+            api.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        } else {
+            for (const char* n : names) {      // 1. whatever RCCL this process already mapped (torch's)
+                api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
+                if (api.lib) break;
+            }
+            for (int i = 0; !api.lib && i < 3; ++i) api.lib = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);   // 2. the system's
         }
-        for (int i = 0; !api.lib && i < 3; ++i) api.lib = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);   // 2. the system's
-        if (!api.lib) { api.error = std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "?"); return; }
+        if (!api.lib) {
+            const char* why = dlerror();                  // (one call: dlerror() clears the message it returns)
+            api.error = std::string("cannot load RCCL: ") + (why ? why : "?");
+            return;
+        }
         auto sym = [&](const char* s) {
             void* p = dlsym(api.lib, s);
             if (!p && api.error.empty()) api.error = std::string("RCCL symbol missing: ") + s;

@@ -353,7 +353,7 @@ static void dma_launch(const ConvArgs& a, hipStream_t st) {
     ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
     const int groups = (a.npt + 7) / 8;
     const int grid = groups * 8 * a.nct;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::LDS_BYTES, st, a);
+    VR_LAUNCH(kern, dim3(grid), dim3(256), Cfg::LDS_BYTES, st, a);
     VR_HIP(hipGetLastError());
 }
 
@@ -622,7 +622,7 @@ void launch_s2d_fused(const ConvArgs& a_in, hipStream_t st) {
     static std::atomic<unsigned long long> attr_done{0};
     ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
     const int groups = (a.npt + 7) / 8;
-    hipLaunchKernelGGL(kern, dim3(groups * 8 * a.nct), dim3(256), Cfg::LDS_BYTES, st, a);
+    VR_LAUNCH(kern, dim3(groups * 8 * a.nct), dim3(256), Cfg::LDS_BYTES, st, a);
     VR_HIP(hipGetLastError());
 }
 

@@ -266,7 +266,7 @@ static void thin_launch(const ConvArgs& a, hipStream_t st) {
     static std::atomic<unsigned long long> attr_done{0};
     ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
     const int groups = (a.npt + 7) / 8;
-    hipLaunchKernelGGL(kern, dim3(groups * 8), dim3(256), Cfg::LDS_BYTES, st, a);
+    VR_LAUNCH(kern, dim3(groups * 8), dim3(256), Cfg::LDS_BYTES, st, a);
     VR_HIP(hipGetLastError());
 }
 

@@ -408,7 +408,7 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, float* __restri
 
 void launch_wino_weights(const float* w, float* u, int Cin, int CoutPad, hipStream_t st) {
     const long long n = (long long)Cin * CoutPad;
-    hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, u, Cin, CoutPad);
+    VR_LAUNCH(wino_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, u, Cin, CoutPad);
     VR_HIP(hipGetLastError());
 }
 
@@ -463,7 +463,7 @@ __global__ void wino_weights_batched_kernel(const WinoWDesc* __restrict__ d, int
 
 void launch_wino_weights_batched(const WinoWDesc* d_descs, int n, long long max_elems, bool split6, hipStream_t st) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(wino_weights_batched_kernel, dim3((unsigned)((max_elems + 255) / 256), (unsigned)n), dim3(256), 0, st, d_descs,
+    VR_LAUNCH(wino_weights_batched_kernel, dim3((unsigned)((max_elems + 255) / 256), (unsigned)n), dim3(256), 0, st, d_descs,
                        split6 ? 1 : 0);
     VR_HIP(hipGetLastError());
 }
@@ -472,7 +472,7 @@ size_t wino_weights6_bytes(int Cin, int CoutPad) { return (size_t)((Cin + 7) / 8
 
 void launch_wino_weights6(const float* w, void* u6, int Cin, int CoutPad, hipStream_t st) {
     const long long n = (long long)((Cin + 7) / 8 * 8) * CoutPad;
-    hipLaunchKernelGGL(wino_weights6_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w,
+    VR_LAUNCH(wino_weights6_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w,
                        static_cast<unsigned short*>(u6), Cin, CoutPad);
     VR_HIP(hipGetLastError());
 }
@@ -485,7 +485,7 @@ static void wino_launch(const ConvArgs& a, hipStream_t st) {
     ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
     const int groups = (a.npt + 7) / 8;
     const int grid = groups * 8 * a.nct;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), Cfg::LDS_BYTES, st, a);
+    VR_LAUNCH(kern, dim3(grid), dim3(512), Cfg::LDS_BYTES, st, a);
     VR_HIP(hipGetLastError());
 }
 

@@ -289,7 +289,7 @@ static void ws_launch(const ConvArgs& a, hipStream_t st) {
     ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
     const int groups = (a.npt + 7) / 8;
     const int grid = groups * 8 * a.nct;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, a);
+    VR_LAUNCH(kern, dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, a);
     VR_HIP(hipGetLastError());
 }
 

@@ -375,6 +375,10 @@ __global__ __launch_bounds__(256, (X3Cfg<MT, TH>::OCC)) void conv_x3_kernel(cons
         chunk(k, P0{});
         if (k + 1 < nchunk) chunk(k + 1, P1{});
     }
+    // The last prefetch (chunk nchunk-2, or the prologue when nchunk == 1) targets channels beyond Cin through an empty descriptor:
+    // nothing waits for those zero-returning loads inside the loop, and hipcc does not track inline-asm loads -- drain them before
+    // the epilogue may reuse the xr[] registers for addresses or old destination values.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---------------- epilogue (conv_epilogue.h): bias, (eval) BatchNorm + activation, up to three destination segments ---------
     if (dbg == 4) return;
@@ -460,13 +464,13 @@ size_t x3_weights_bytes(int Cin, int KK, int CoutPad) { return (size_t)((Cin + 7
 
 void launch_x3_weights(const float* w, void* o, int Cin, int KK, int CoutPad, hipStream_t st) {
     const long long n = (long long)((Cin + 7) / 8 * 8) * KK * CoutPad;
-    hipLaunchKernelGGL(x3_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, static_cast<unsigned short*>(o), Cin, KK,
+    VR_LAUNCH(x3_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, static_cast<unsigned short*>(o), Cin, KK,
                        CoutPad);
     VR_HIP(hipGetLastError());
 }
 void launch_x3_weights_batched(const X3WDesc* d_descs, int n, long long max_elems, hipStream_t st) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(x3_weights_batched_kernel, dim3((unsigned)((max_elems + 255) / 256), (unsigned)n), dim3(256), 0, st, d_descs);
+    VR_LAUNCH(x3_weights_batched_kernel, dim3((unsigned)((max_elems + 255) / 256), (unsigned)n), dim3(256), 0, st, d_descs);
     VR_HIP(hipGetLastError());
 }
 
@@ -477,7 +481,7 @@ static void x3_launch(const ConvArgs& a, hipStream_t st) {
     static std::atomic<unsigned long long> attr_done{0};
     ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
     const int groups = (a.npt + 7) / 8;
-    hipLaunchKernelGGL(kern, dim3(groups * 8 * a.nct), dim3(256), Cfg::LDS_BYTES, st, a);
+    VR_LAUNCH(kern, dim3(groups * 8 * a.nct), dim3(256), Cfg::LDS_BYTES, st, a);
     VR_HIP(hipGetLastError());
 }
 

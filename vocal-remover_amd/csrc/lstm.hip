@@ -127,9 +127,9 @@ void launch_bilstm_train(const float* gx, const float* whh_f, const float* whh_r
                          int N, int T, int H, hipStream_t st) {
     static const bool reg_form = !getenv("VR_LSTM_LDS");
     if (reg_form && (H == 64 || H == 32 || H == 16)) {
-        if (H == 64) hipLaunchKernelGGL(bilstm_reg_kernel<64>, dim3(N, 2), dim3(256), 0, st, gx, whh_f, whh_r, out, save, T);
-        else if (H == 32) hipLaunchKernelGGL(bilstm_reg_kernel<32>, dim3(N, 2), dim3(128), 0, st, gx, whh_f, whh_r, out, save, T);
-        else hipLaunchKernelGGL(bilstm_reg_kernel<16>, dim3(N, 2), dim3(64), 0, st, gx, whh_f, whh_r, out, save, T);
+        if (H == 64) VR_LAUNCH(bilstm_reg_kernel<64>, dim3(N, 2), dim3(256), 0, st, gx, whh_f, whh_r, out, save, T);
+        else if (H == 32) VR_LAUNCH(bilstm_reg_kernel<32>, dim3(N, 2), dim3(128), 0, st, gx, whh_f, whh_r, out, save, T);
+        else VR_LAUNCH(bilstm_reg_kernel<16>, dim3(N, 2), dim3(64), 0, st, gx, whh_f, whh_r, out, save, T);
         VR_HIP(hipGetLastError());
         return;
     }
@@ -140,7 +140,7 @@ void launch_bilstm_train(const float* gx, const float* whh_f, const float* whh_r
     VR_CHECK(lds <= 160 * 1024, -2, "LSTM W_hh does not fit LDS");
     static std::atomic<unsigned long long> attr_done{0};          // per device (bit = device index)
     ensure_lds_attr(attr_done, reinterpret_cast<const void*>(bilstm_kernel), 160 * 1024);
-    hipLaunchKernelGGL(bilstm_kernel, dim3(N, 2), dim3(threads), lds, st, gx, whh_f, whh_r, out, save, T, H);
+    VR_LAUNCH(bilstm_kernel, dim3(N, 2), dim3(threads), lds, st, gx, whh_f, whh_r, out, save, T, H);
     VR_HIP(hipGetLastError());
 }
 
@@ -275,9 +275,9 @@ void launch_bilstm_bwd(const float* dh, const float* save, const float* whh_f, c
                        int N, int T, int H, hipStream_t st) {
     static const bool reg_form = !getenv("VR_LSTM_LDS");
     if (reg_form && (H == 64 || H == 32 || H == 16)) {
-        if (H == 64) hipLaunchKernelGGL(bilstm_bwd_reg_kernel<64>, dim3(N, 2), dim3(256), 0, st, dh, save, whh_f, whh_r, dgx, T);
-        else if (H == 32) hipLaunchKernelGGL(bilstm_bwd_reg_kernel<32>, dim3(N, 2), dim3(128), 0, st, dh, save, whh_f, whh_r, dgx, T);
-        else hipLaunchKernelGGL(bilstm_bwd_reg_kernel<16>, dim3(N, 2), dim3(64), 0, st, dh, save, whh_f, whh_r, dgx, T);
+        if (H == 64) VR_LAUNCH(bilstm_bwd_reg_kernel<64>, dim3(N, 2), dim3(256), 0, st, dh, save, whh_f, whh_r, dgx, T);
+        else if (H == 32) VR_LAUNCH(bilstm_bwd_reg_kernel<32>, dim3(N, 2), dim3(128), 0, st, dh, save, whh_f, whh_r, dgx, T);
+        else VR_LAUNCH(bilstm_bwd_reg_kernel<16>, dim3(N, 2), dim3(64), 0, st, dh, save, whh_f, whh_r, dgx, T);
         VR_HIP(hipGetLastError());
         return;
     }
@@ -287,7 +287,7 @@ void launch_bilstm_bwd(const float* dh, const float* save, const float* whh_f, c
     VR_CHECK(G <= 1024 && lds <= 160 * 1024, -2, "LSTM hidden size too large for the LDS-resident backward");
     static std::atomic<unsigned long long> attr_done{0};          // per device (bit = device index)
     ensure_lds_attr(attr_done, reinterpret_cast<const void*>(bilstm_bwd_kernel), 160 * 1024);
-    hipLaunchKernelGGL(bilstm_bwd_kernel, dim3(N, 2), dim3(threads), lds, st, dh, save, whh_f, whh_r, dgx, T, H);
+    VR_LAUNCH(bilstm_bwd_kernel, dim3(N, 2), dim3(threads), lds, st, dh, save, whh_f, whh_r, dgx, T, H);
     VR_HIP(hipGetLastError());
 }
 
@@ -387,10 +387,10 @@ size_t lstm_whh_grad_scratch_floats(int N, int H) { return (size_t)whh_slices(N)
 void launch_lstm_whh_grad(const float* dgx, const float* hout, float* dwhh_f, float* dwhh_r, int N, int T, int H,
                           int accumulate, float* part, hipStream_t st) {
     const int ns = whh_slices(N), GH = 4 * H * H;
-    hipLaunchKernelGGL(lstm_whh_grad_kernel, dim3((4 * H + 15) / 16, 2 * ns, (H + 63) / 64), dim3(256), 0, st, dgx, hout, part, N, T,
+    VR_LAUNCH(lstm_whh_grad_kernel, dim3((4 * H + 15) / 16, 2 * ns, (H + 63) / 64), dim3(256), 0, st, dgx, hout, part, N, T,
                        H, ns);
     VR_HIP(hipGetLastError());
-    hipLaunchKernelGGL(lstm_whh_reduce_kernel, dim3((GH + 255) / 256, 2), dim3(256), 0, st, part, dwhh_f, dwhh_r, GH, ns, accumulate);
+    VR_LAUNCH(lstm_whh_reduce_kernel, dim3((GH + 255) / 256, 2), dim3(256), 0, st, part, dwhh_f, dwhh_r, GH, ns, accumulate);
     VR_HIP(hipGetLastError());
 }
 

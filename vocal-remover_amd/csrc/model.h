@@ -93,7 +93,6 @@ void comm_unique_id(void* out128);                       // ncclGetUniqueId (com
 void merge_artifacts_weight(const std::vector<float>& fmin, std::vector<float>& weight, float thres, int min_range,
                             int fade);
 
-struct ProfileEntry { hipEvent_t e0, e1; double flops; int kind; std::string tag; double bytes = 0; };
 
 class Model {
 public:
@@ -144,7 +143,8 @@ public:
 
     // ---- profiling ----
     bool profiling = false;
-    std::vector<ProfileEntry> prof;
+    LaunchProfiler* launch_prof = nullptr;               // profile.hip: every VR_LAUNCH of a profiled step, timed on its own stream
+    std::string profile_report;                          // per-kernel-name totals of the last profiled step (vr_profile_report)
     void profile_begin();
     void augment_api(const float* Xc, const float* yc, const float* Xi, const float* yi, const void* desc, const float* rw,
                      int B, int T, int bins, bool in_on_dev, float* Xmag, float* ymag, bool out_on_dev);
@@ -311,6 +311,8 @@ private:
     const float* dropout_dev = nullptr;                  // [5][N][Cmax] keep-masks (training), or null
     void plan_and_reserve(int B, int T, size_t extra_bytes);
     void record_begin(int kind, double flops);
+    void record_note(double bytes, const char* tag);
+    double conv_alg_bytes(const Conv& L, const ConvArgs& a, int N, bool batch_as_h) const;
     void record_end();
 };
 

@@ -235,6 +235,8 @@ void Model::finalize_layout() {
 }
 
 Model::~Model() {
+    if (g_launch_prof == launch_prof) g_launch_prof = nullptr;
+    prof_destroy(launch_prof);
     int prev_dev = -1;
     if (hipGetDevice(&prev_dev) != hipSuccess) prev_dev = -1;
     hipSetDevice(device);
@@ -514,47 +516,44 @@ void Model::ensure_io(size_t bytes) {
     io.cap = want;
 }
 
+// Algorithmic HBM bytes of one convolution launch -- forward, data gradient or weight gradient alike: the (virtual) input-sized
+// tensor, the output-sized tensor and the weights, each crossing HBM once.
+double Model::conv_alg_bytes(const Conv& L, const ConvArgs& a, int N, bool batch_as_h) const {
+    return 4.0 * ((double)a.N * L.Cin * a.Hin * a.Win + (double)N * L.Cout * (batch_as_h ? 1 : a.Hout) * a.Wout +
+                  (double)L.Cin * L.KS * L.KS * L.Cout);
+}
+
+// The executor's note for the next launch: a convolution's algorithmic FLOPs (bytes / tag follow through record_note).
 void Model::record_begin(int kind, double flops) {
     if (!profiling || dry) return;
-    ProfileEntry e{};
-    VR_HIP(hipEventCreate(&e.e0));
-    VR_HIP(hipEventCreate(&e.e1));
-    e.flops = flops; e.kind = kind;
-    VR_HIP(hipEventRecord(e.e0, stream));
-    prof.push_back(e);
+    (void)kind;
+    prof_note(flops, 0.0, true, "conv");
+}
+void Model::record_note(double bytes, const char* tag) {
+    if (!profiling || dry || !g_launch_prof) return;
+    prof_note_update(bytes, tag);
 }
 void Model::record_end() {
     if (!profiling || dry) return;
-    VR_HIP(hipEventRecord(prof.back().e1, stream));
+    prof_note_clear();                                   // (a dispatcher that launched nothing leaves no stale note)
 }
 
 void Model::profile_begin() {
-    for (auto& e : prof) { hipEventDestroy(e.e0); hipEventDestroy(e.e1); }
-    prof.clear();
+    prof_destroy(launch_prof);
+    launch_prof = prof_create();
+    g_launch_prof = launch_prof;
     profiling = true;
 }
 
 void Model::profile_end(double* conv_ms, double* conv_flops, double* conv_bytes, int* launches) {
     DeviceGuard dev_guard(device);
-    VR_HIP(hipStreamSynchronize(stream));
-    double cm = 0, cf = 0, om = 0, cb = 0;
-    int n = 0;
-    for (auto& e : prof) {
-        float ms = 0.f;
-        VR_HIP(hipEventElapsedTime(&ms, e.e0, e.e1));
-        if (e.kind == 0) { cm += ms; cf += e.flops; cb += e.bytes; ++n; } else om += ms;
-        static const bool dump = getenv("VR_PROFILE_DUMP") != nullptr;       // per-launch table on stderr
-        if (dump) fprintf(stderr, "[vr-prof] %-44s %9.1f us %8.2f GFLOP %7.1f TFLOP/s\n", e.tag.c_str(), ms * 1e3,
-                          e.flops * 1e-9, ms > 0 ? e.flops / ms * 1e-9 : 0.0);
-        hipEventDestroy(e.e0); hipEventDestroy(e.e1);
-    }
-    prof.clear();
+    VR_HIP(hipDeviceSynchronize());                      // every stream the profiled step used
+    g_launch_prof = nullptr;
     profiling = false;
-    if (conv_ms) *conv_ms = cm;
-    if (conv_flops) *conv_flops = cf;
-    if (conv_bytes) *conv_bytes = cb;
-    (void)om;
-    if (launches) *launches = n;
+    static const bool dump = getenv("VR_PROFILE_DUMP") != nullptr;           // per-launch table on stderr
+    if (launch_prof) prof_collect(launch_prof, conv_ms, conv_flops, conv_bytes, launches, &profile_report, dump);
+    prof_destroy(launch_prof);
+    launch_prof = nullptr;
 }
 
 void Model::tap(const std::string& name, const Tensor& t) {
@@ -741,12 +740,10 @@ Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs_in, int N, cons
         record_begin(0, flops);
         if (profiling) {
             // algorithmic HBM bytes of the launch: the virtual input, the 3x3/1x1 weights and the output, once each
-            prof.back().bytes = 4.0 * ((double)a.N * L.Cin * a.Hin * a.Win + (double)N * L.Cout * (batch_as_h ? 1 : a.Hout) * a.Wout +
-                                       (double)L.Cin * L.KS * L.KS * L.Cout);
             char tag[160];
             snprintf(tag, sizeof tag, "%s k%d s%d d%d ci%d co%d %dx%dx%d", L.name.c_str(), L.KS, L.stride, L.dh, L.Cin,
                      L.Cout, a.N, a.Hout, a.Wout);
-            prof.back().tag = tag;
+            record_note(conv_alg_bytes(L, a, N, batch_as_h), tag);
         }
         launch_conv(a, shp, stream);
         record_end();
@@ -1070,9 +1067,9 @@ void Model::forward_api(const float* x, bool x_on_device, int B, int T, int mode
     struct FwdOnly { Model* m; ~FwdOnly() { m->fwd_only = false; m->dropout_dev = nullptr; } } fwd_scope{this};
     fwd_only = training;
     if (training) refresh_wino(false);      // before planning: the kernel choice (and its partial-statistics layout) depends on them
+    if (!training) fold_eval_affines();     // (eval: the bf16-plane weight tables decide conv_x3 vs the materialised-upsample plan)
     plan_and_reserve(B, T, (in_floats + out_floats) * sizeof(float) + 1024);
-    if (!training) fold_eval_affines();
-    else prepare_dropout(B);
+    if (training) prepare_dropout(B);
     float* xd = ws.allocf(in_floats);
     float* od = out_on_device ? out : ws.allocf(out_floats);
     if (x_on_device) VR_HIP(hipMemcpyAsync(xd, x, in_floats * sizeof(float), hipMemcpyDeviceToDevice, stream));
@@ -1088,7 +1085,7 @@ void Model::forward_api(const float* x, bool x_on_device, int B, int T, int mode
     launch_head_sigmoid(f3, out_w->dev, d, stream);
     if (mode == 2) {
         const long long total = (long long)out_floats;
-        hipLaunchKernelGGL(mul_crop_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, xd, od, T, Wm,
+        VR_LAUNCH(mul_crop_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, xd, od, T, Wm,
                            offset, total);
         VR_HIP(hipGetLastError());
     }
@@ -1125,8 +1122,8 @@ void Model::validate_api(const float* X, const float* Y, bool on_dev, int B, int
     const int Wm = T - 2 * offset;
     const size_t out_floats = (size_t)B * 2 * output_bin * Wm;
     const int nblk = 1024;
+    fold_eval_affines();                    // before planning, as in forward_api
     plan_and_reserve(B, T, (2 * in_floats + out_floats + nblk + 64) * sizeof(float) + 8192);
-    fold_eval_affines();
     float* xd = ws.allocf(in_floats);
     const float* yd = Y;
     const hipMemcpyKind kind = on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
@@ -1148,9 +1145,9 @@ void Model::validate_api(const float* X, const float* Y, bool on_dev, int B, int
     d.w_lo = offset; d.w_hi = T - offset; d.pad_rows = output_bin - max_bin;
     launch_head_sigmoid(f3, out_w->dev, d, stream);
     const long long total = (long long)out_floats;
-    hipLaunchKernelGGL(mul_crop_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, xd, od, T, Wm, offset, total);
+    VR_LAUNCH(mul_crop_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, xd, od, T, Wm, offset, total);
     VR_HIP(hipGetLastError());
-    hipLaunchKernelGGL(l1_crop_kernel, dim3(nblk), dim3(256), 0, stream, od, yd, T, Wm, offset, total, part);
+    VR_LAUNCH(l1_crop_kernel, dim3(nblk), dim3(256), 0, stream, od, yd, T, Wm, offset, total, part);
     VR_HIP(hipGetLastError());
     launch_reduce_rows(part, 1, nblk, lossd, 1, 0, (float)(1.0 / (double)total), stream);
     float loss_h = 0.f;
@@ -1299,8 +1296,8 @@ void Model::separate_api(const float* spec, bool on_dev, int T, int tta, int bat
         max_patches = std::max(max_patches, (Wpad - 2 * offset) / roi);
     }
     const int bs = (batchsize <= 0) ? max_patches : std::min(batchsize, max_patches);
+    fold_eval_affines();                    // before planning, as in forward_api
     plan_and_reserve(bs, cropsize, 0);
-    fold_eval_affines();
     for (int ps = 0; ps < npass; ++ps) {
         const int pl = pad_l + (ps ? roi / 2 : 0), pr = pad_r + (ps ? roi / 2 : 0);
         const int Wpad = T + pl + pr;
@@ -1308,7 +1305,7 @@ void Model::separate_api(const float* spec, bool on_dev, int T, int tta, int bat
         float* mag = io.allocf((size_t)2 * bins * Wpad);
         Wm[ps] = patches * roi;
         mask[ps] = io.allocf((size_t)2 * bins * Wm[ps]);
-        VR_HIP(hipMemsetAsync(mag, 0, (size_t)2 * bins * Wpad * sizeof(float), stream));
+        prof_memset_async(mag, 0, (size_t)2 * bins * Wpad * sizeof(float), stream);
         launch_mag_pad(reinterpret_cast<const float2*>(sd), bins, T, mag, Wpad, pl, stats, stream);
         launch_coef_affine(stats, 2 * bins, tta ? 1 : 0, in_aff, stream);
         {   // X_mag / coef once, so that the first conv of every BaseNet reads a plain tensor (LDS-DMA path)

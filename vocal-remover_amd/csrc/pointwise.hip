@@ -108,7 +108,8 @@ void launch_head_sigmoid(const Tensor& x, const float* w, const HeadDst& d, hipS
     check_vec4(x);
     const long long total = (long long)x.N * x.H * (x.W / 4);
     const int grid = (int)((total + 255) / 256);
-    hipLaunchKernelGGL((thin_conv_kernel<2, true>), dim3(grid), dim3(256), 0, st, x, w, d, nullptr, nullptr, nullptr);
+    prof_note(2.0 * 2 * x.C * (double)x.N * x.H * x.W, 4.0 * ((double)x.N * x.C * x.H * x.W + 2.0 * x.N * x.H * x.W));   // C -> 2 head
+    VR_LAUNCH((thin_conv_kernel<2, true>), dim3(grid), dim3(256), 0, st, x, w, d, nullptr, nullptr, nullptr);
     VR_HIP(hipGetLastError());
 }
 
@@ -118,7 +119,8 @@ int launch_squeeze_conv(const Tensor& x, const float* w, float* out, float* part
     if (dry) return grid;
     check_vec4(x);
     HeadDst d{};
-    hipLaunchKernelGGL((thin_conv_kernel<1, false>), dim3(grid), dim3(256), 0, st, x, w, d, out, part, epi);
+    prof_note(2.0 * x.C * (double)x.N * x.H * x.W, 4.0 * ((double)x.N * x.C * x.H * x.W + (double)x.N * x.H * x.W));
+    VR_LAUNCH((thin_conv_kernel<1, false>), dim3(grid), dim3(256), 0, st, x, w, d, out, part, epi);
     VR_HIP(hipGetLastError());
     return grid;
 }
@@ -143,7 +145,7 @@ __global__ void avgpool_h_kernel(Tensor x, float* out) {
 
 void launch_avgpool_h(const Tensor& x, float* out, hipStream_t st) {
     const int total = x.N * x.C * x.W;
-    hipLaunchKernelGGL(avgpool_h_kernel, dim3((total + 255) / 256), dim3(256), 0, st, x, out);
+    VR_LAUNCH(avgpool_h_kernel, dim3((total + 255) / 256), dim3(256), 0, st, x, out);
     VR_HIP(hipGetLastError());
 }
 
@@ -161,7 +163,7 @@ __global__ void bn_fold_eval_kernel(const BNFoldDesc* descs, float eps) {
 }
 
 void launch_bn_fold_eval(const BNFoldDesc* d_descs, int ndesc, int maxC, float eps, hipStream_t st) {
-    hipLaunchKernelGGL(bn_fold_eval_kernel, dim3((maxC + 127) / 128, ndesc), dim3(128), 0, st, d_descs, eps);
+    VR_LAUNCH(bn_fold_eval_kernel, dim3((maxC + 127) / 128, ndesc), dim3(128), 0, st, d_descs, eps);
     VR_HIP(hipGetLastError());
 }
 
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(BNFinalizeArgs a) {
 }
 
 void launch_bn_finalize(const BNFinalizeArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(a.C), dim3(256), 0, st, a);
+    VR_LAUNCH(bn_finalize_kernel, dim3(a.C), dim3(256), 0, st, a);
     VR_HIP(hipGetLastError());
 }
 
@@ -218,7 +220,7 @@ __global__ void rows_affine_relu_kernel(const float* x, float* out, const float*
 
 void launch_rows_affine_relu(const float* x, float* out, const float* aff, int N, int R, int W, hipStream_t st) {
     const long long total = (long long)N * R * W;
-    hipLaunchKernelGGL(rows_affine_relu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, out, aff, R, W, total);
+    VR_LAUNCH(rows_affine_relu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, out, aff, R, W, total);
     VR_HIP(hipGetLastError());
 }
 
@@ -228,7 +230,7 @@ __global__ void add_kernel(const float* a, const float* b, float* out, int n) {
 }
 
 void launch_add(const float* a, const float* b, float* out, int n, hipStream_t st) {
-    hipLaunchKernelGGL(add_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, b, out, n);
+    VR_LAUNCH(add_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, b, out, n);
     VR_HIP(hipGetLastError());
 }
 
@@ -357,22 +359,23 @@ void launch_upsample2x(const Tensor& x, float* out, hipStream_t st) {
     const long long total = (long long)x.N * x.C * x.H * x.W * 4;
     static const bool rows = !getenv("VR_NO_UP_ROWS");
     const long long nrows = (long long)x.N * x.C * 2 * x.H;
+    prof_note(0.0, 4.0 * 5.0 * (double)x.N * x.C * x.H * x.W);          // reads the low-resolution tensor, writes 4x as much
     if (rows && (x.W & 1) == 0 && x.W >= 8 && nrows < 0x7FFFFFFFLL && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
         const int quads = 2 * x.W / 4;
         int qp = 2;                                            // threads per row: power of two >= quads, 4 .. 256
         while ((1 << qp) < quads && qp < 8) ++qp;
         const int rpb = 256 >> qp;
-        hipLaunchKernelGGL(upsample2x_rows_kernel, dim3((unsigned)((nrows + rpb - 1) / rpb), qp >= 8 ? (quads + 255) / 256 : 1), dim3(256),
+        VR_LAUNCH(upsample2x_rows_kernel, dim3((unsigned)((nrows + rpb - 1) / rpb), qp >= 8 ? (quads + 255) / 256 : 1), dim3(256),
                            0, st, x, out, rh, rw, qp, nrows);
         VR_HIP(hipGetLastError());
         return;
     }
     if ((x.W & 1) == 0) {
         const long long tv = total / 4;
-        hipLaunchKernelGGL(upsample2x_kernel<4>, dim3((unsigned)((tv + 255) / 256)), dim3(256), 0, st, x, out, rh, rw, tv);
+        VR_LAUNCH(upsample2x_kernel<4>, dim3((unsigned)((tv + 255) / 256)), dim3(256), 0, st, x, out, rh, rw, tv);
     } else {
         const long long tv = total / 2;
-        hipLaunchKernelGGL(upsample2x_kernel<2>, dim3((unsigned)((tv + 255) / 256)), dim3(256), 0, st, x, out, rh, rw, tv);
+        VR_LAUNCH(upsample2x_kernel<2>, dim3((unsigned)((tv + 255) / 256)), dim3(256), 0, st, x, out, rh, rw, tv);
     }
     VR_HIP(hipGetLastError());
 }
@@ -401,13 +404,14 @@ __global__ __launch_bounds__(256) void materialize4_kernel(Tensor x, float* __re
 
 void launch_materialize(const Tensor& x, float* out, hipStream_t st) {
     const long long total = (long long)x.N * x.C * x.H * x.W;
+    prof_note(0.0, 4.0 * (double)((x.sH == 0 && x.H > 0 ? total / x.H : total) + total));     // one read (H-broadcast: one row), one write
     const bool vec = (x.W & 3) == 0 && (x.sH & 3) == 0 && (x.sC & 3) == 0 && (x.sN & 3) == 0 &&
                      (reinterpret_cast<uintptr_t>(x.p) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
     if (vec) {
         const long long t4 = total / 4;
-        hipLaunchKernelGGL(materialize4_kernel, dim3((unsigned)((t4 + 255) / 256)), dim3(256), 0, st, x, out, t4);
+        VR_LAUNCH(materialize4_kernel, dim3((unsigned)((t4 + 255) / 256)), dim3(256), 0, st, x, out, t4);
     } else {
-        hipLaunchKernelGGL(materialize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, out, total);
+        VR_LAUNCH(materialize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, out, total);
     }
     VR_HIP(hipGetLastError());
 }

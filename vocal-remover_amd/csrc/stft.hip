@@ -66,7 +66,7 @@ void launch_stft_tiled(const FFTPlan& pl, const float* wave, long long L, int T,
 
 void launch_stft(const FFTPlan& pl, const float* wave, long long L, int hop, int T, float2* spec, hipStream_t st) {
     if (tiled_signal_path(pl, hop)) { launch_stft_tiled(pl, wave, L, T, spec, st); return; }
-    hipLaunchKernelGGL(stft_kernel, dim3(T, 2), dim3(256), pl.n_fft * sizeof(float2), st, pl, wave, L, hop, T, spec);
+    VR_LAUNCH(stft_kernel, dim3(T, 2), dim3(256), pl.n_fft * sizeof(float2), st, pl, wave, L, hop, T, spec);
     VR_HIP(hipGetLastError());
 }
 
@@ -253,7 +253,9 @@ void launch_istft_masked(const FFTPlan& pl, const float2* spec, int hop, int T, 
     const size_t lds = (size_t)TG * M * 8 + (size_t)bins * F * 8 + (size_t)M * 4;
     static std::atomic<unsigned long long> attr_done{0};
     ensure_lds_attr(attr_done, reinterpret_cast<const void*>(istft_tile_kernel), 160 * 1024);
-    hipLaunchKernelGGL(istft_tile_kernel, dim3((unsigned)((T - 1 + S - 1) / S), 2), dim3(1024), lds, st, pl, spec, T, S, mask_a, Wa,
+    // per stem: the complex spectrogram (8 B per bin-frame), the mask(s) (4 B), hop samples written per frame, two channels
+    prof_note(0.0, 2.0 * ((double)bins * T * (8.0 + 4.0 * (mask_b ? 2 : 1)) + 4.0 * (double)out_len));
+    VR_LAUNCH(istft_tile_kernel, dim3((unsigned)((T - 1 + S - 1) / S), 2), dim3(1024), lds, st, pl, spec, T, S, mask_a, Wa,
                        mask_b, Wb, shift, wgt, which, wave, out_len);
     VR_HIP(hipGetLastError());
 }
@@ -316,7 +318,8 @@ void launch_stft_tiled(const FFTPlan& pl, const float* wave, long long L, int T,
     const size_t lds = (size_t)TG * M * 8 + (size_t)bins * F * 8;
     static std::atomic<unsigned long long> attr_done{0};
     ensure_lds_attr(attr_done, reinterpret_cast<const void*>(stft_tile_kernel), 160 * 1024);
-    hipLaunchKernelGGL(stft_tile_kernel, dim3((unsigned)((T + F - 1) / F), 2), dim3(1024), lds, st, pl, wave, L, T, F, spec);
+    prof_note(0.0, 2.0 * (4.0 * (double)L + 8.0 * (double)bins * T));              // unique audio read once, complex64 spectrogram written
+    VR_LAUNCH(stft_tile_kernel, dim3((unsigned)((T + F - 1) / F), 2), dim3(1024), lds, st, pl, wave, L, T, F, spec);
     VR_HIP(hipGetLastError());
 }
 
@@ -327,11 +330,11 @@ void launch_istft(const FFTPlan& pl, const float2* spec, int hop, int T, float* 
         launch_istft_masked(pl, spec, hop, T, nullptr, 0, nullptr, 0, 0, nullptr, 0, wave, st);
         return;
     }
-    hipLaunchKernelGGL(istft_frame_kernel, dim3(T, 2), dim3(256), pl.n_fft * sizeof(float2), st, pl, spec, T, frames);
+    VR_LAUNCH(istft_frame_kernel, dim3(T, 2), dim3(256), pl.n_fft * sizeof(float2), st, pl, spec, T, frames);
     VR_HIP(hipGetLastError());
     const long long out_len = (long long)hop * (T - 1);
     if (out_len > 0) {
-        hipLaunchKernelGGL(istft_ola_kernel, dim3((unsigned)((out_len + 255) / 256), 2), dim3(256), 0, st, pl, frames,
+        VR_LAUNCH(istft_ola_kernel, dim3((unsigned)((out_len + 255) / 256), 2), dim3(256), 0, st, pl, frames,
                            hop, T, out_len, wave);
         VR_HIP(hipGetLastError());
     }
@@ -355,7 +358,7 @@ __global__ void stats_init_kernel(unsigned* stats) {
     *reinterpret_cast<unsigned long long*>(stats + 2) = key;
 }
 void launch_stats_init(unsigned* stats, hipStream_t st) {
-    hipLaunchKernelGGL(stats_init_kernel, dim3(1), dim3(1), 0, st, stats);
+    VR_LAUNCH(stats_init_kernel, dim3(1), dim3(1), 0, st, stats);
     VR_HIP(hipGetLastError());
 }
 
@@ -396,7 +399,8 @@ __global__ __launch_bounds__(256) void mag_pad_kernel(const float2* __restrict__
 
 void launch_mag_pad(const float2* spec, int bins, int T, float* mag_pad, int Wpad, int pad_l, unsigned* stats,
                     hipStream_t st) {
-    hipLaunchKernelGGL(mag_pad_kernel, dim3(2 * bins), dim3(256), 0, st, spec, T, mag_pad, Wpad, pad_l,
+    prof_note(0.0, 2.0 * (double)bins * (8.0 * T + 4.0 * Wpad));
+    VR_LAUNCH(mag_pad_kernel, dim3(2 * bins), dim3(256), 0, st, spec, T, mag_pad, Wpad, pad_l,
                        reinterpret_cast<unsigned long long*>(stats) + 2);
     VR_HIP(hipGetLastError());
 }
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(256) void coef_affine_kernel(const unsigned* stats,
     }
 }
 void launch_coef_affine(const unsigned* stats, int rows, int mode, float* aff, hipStream_t st) {
-    hipLaunchKernelGGL(coef_affine_kernel, dim3(1), dim3(256), 0, st, stats, rows, mode, aff);
+    VR_LAUNCH(coef_affine_kernel, dim3(1), dim3(256), 0, st, stats, rows, mode, aff);
     VR_HIP(hipGetLastError());
 }
 
@@ -462,7 +466,7 @@ __global__ __launch_bounds__(256) void frame_min_kernel(int rows, int T, const f
 
 void launch_frame_min(int bins, int T, const float* mask_a, int Wa, const float* mask_b, int Wb, int shift, float* fmin,
                       hipStream_t st) {
-    hipLaunchKernelGGL(frame_min_kernel, dim3((T + 63) / 64), dim3(256), 0, st, 2 * bins, T, mask_a, Wa, mask_b, Wb, shift, fmin);
+    VR_LAUNCH(frame_min_kernel, dim3((T + 63) / 64), dim3(256), 0, st, 2 * bins, T, mask_a, Wa, mask_b, Wb, shift, fmin);
     VR_HIP(hipGetLastError());
 }
 
@@ -486,7 +490,7 @@ __global__ void apply_mask_kernel(const float2* __restrict__ spec, int bins, int
 void launch_apply_mask(const float2* spec, int bins, int T, const float* mask_a, int Wa, const float* mask_b, int Wb,
                        int shift, const float* wgt, float2* y, float2* v, hipStream_t st) {
     const long long total = 2LL * bins * T;
-    hipLaunchKernelGGL(apply_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, spec, bins, T, mask_a,
+    VR_LAUNCH(apply_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, spec, bins, T, mask_a,
                        Wa, mask_b, Wb, shift, wgt, y, v);
     VR_HIP(hipGetLastError());
 }

@@ -70,7 +70,7 @@ void Model::ensure_train_state() {
 void Model::zero_grad_api() {
     DeviceGuard dev_guard(device);
     ensure_train_state();
-    VR_HIP(hipMemsetAsync(g_arena, 0, p_floats * sizeof(float), stream));
+    prof_memset_async(g_arena, 0, p_floats * sizeof(float), stream);
     VR_HIP(hipStreamSynchronize(stream));
 }
 
@@ -123,7 +123,7 @@ void Model::prepare_dropout(int B) {
         VR_CHECK(dropout_host.size() == n, -2, "injected dropout masks were given for a different batch size");
         VR_HIP(hipMemcpyAsync(dropout_buf, dropout_host.data(), n * sizeof(float), hipMemcpyHostToDevice, stream));
     } else {
-        hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dropout_buf, (long long)n,
+        VR_LAUNCH(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dropout_buf, (long long)n,
                            dropout_seed, train_calls);
         VR_HIP(hipGetLastError());
     }
@@ -181,6 +181,7 @@ void Model::bwd_conv(TapeRec& r) {
                 wgrad_on_side = true;
             }
             record_begin(0, 2.0 * N * (double)(r.batch_as_h ? 1 : f.Hout) * f.Wout * (double)L.Cout * L.Cin * L.KS * L.KS);
+            record_note(conv_alg_bytes(L, f, N, r.batch_as_h), ("wgrad " + L.name).c_str());
             launch_wgrad(w, shp, grad_of(L.w), 1, wst);
             record_end();
         }
@@ -260,6 +261,7 @@ void Model::bwd_conv(TapeRec& r) {
                 k.s2_cls_stride = (long long)cls_stride; k.s2_H = f.Hin; k.s2_W = f.Win;
                 if (s2d_fused_eligible(k)) {
                     record_begin(0, 2.0 * N * (double)f.Hout * f.Wout * (double)L.Cout * L.Cin * L.KS * L.KS);
+                    record_note(conv_alg_bytes(L, f, N, false), ("dgrad " + L.name).c_str());
                     launch_s2d_fused(k, stream);
                     record_end();
                     return;
@@ -284,7 +286,10 @@ void Model::bwd_conv(TapeRec& r) {
                     k.dst[i].wshift = 1;
                 }
                 if (cls == 0 && !conv_dma_eligible(k, cshp)) { ok = false; break; }
-                if (cls == 0) record_begin(0, 2.0 * N * (double)f.Hout * f.Wout * (double)L.Cout * L.Cin * L.KS * L.KS);
+                if (cls == 0) {
+                    record_begin(0, 2.0 * N * (double)f.Hout * f.Wout * (double)L.Cout * L.Cin * L.KS * L.KS);
+                    record_note(conv_alg_bytes(L, f, N, false), ("dgrad " + L.name).c_str());
+                }
                 launch_conv(k, cshp, stream);
             }
             if (ok) { record_end(); return; }
@@ -292,6 +297,7 @@ void Model::bwd_conv(TapeRec& r) {
     }
     const ConvShape dshp{L.KS, 1, L.dh, L.dw};
     record_begin(0, 2.0 * N * (double)(r.batch_as_h ? 1 : f.Hout) * f.Wout * (double)L.Cout * L.Cin * L.KS * L.KS);
+    record_note(conv_alg_bytes(L, f, N, r.batch_as_h), ("dgrad " + L.name).c_str());
     launch_conv(d, dshp, stream);
     record_end();
     for (auto& p : posts) {
@@ -442,11 +448,11 @@ void Model::train_fwd_bwd_api(const float* X, const float* Y, bool on_dev, int B
         if (!lanes.empty()) {
             VR_HIP(hipEventRecord(lanes[0].fork, stream));            // (previous step's consumers of gs are done)
             VR_HIP(hipStreamWaitEvent(lanes[0].main, lanes[0].fork, 0));
-            VR_HIP(hipMemsetAsync(gs.base, 0, need_gs, lanes[0].main));
+            prof_memset_async(gs.base, 0, need_gs, lanes[0].main);
             VR_HIP(hipEventRecord(lanes[0].join, lanes[0].main));
             gs_clear_pending = true;
         } else {
-            VR_HIP(hipMemsetAsync(gs.base, 0, need_gs, stream));
+            prof_memset_async(gs.base, 0, need_gs, stream);
         }
     }
     prepare_dropout(B);
@@ -524,7 +530,7 @@ void Model::forward_train_api(const float* X, bool on_dev, int B, int T, float* 
         }
         ws.reset(); gs.reset();
         if (gs_clear_pending) { VR_HIP(hipStreamWaitEvent(stream, lanes[0].join, 0)); gs_clear_pending = false; }
-        VR_HIP(hipMemsetAsync(gs.base, 0, need_gs, stream));
+        prof_memset_async(gs.base, 0, need_gs, stream);
     }
     prepare_dropout(B);
     float* xd = ws.allocf(io_floats);
@@ -624,8 +630,8 @@ void Model::reset_adam_state() {
     DeviceGuard dev_guard(device);
     adam_step = 0;
     if (m_arena) {
-        VR_HIP(hipMemsetAsync(m_arena, 0, p_floats * sizeof(float), stream));
-        VR_HIP(hipMemsetAsync(v_arena, 0, p_floats * sizeof(float), stream));
+        prof_memset_async(m_arena, 0, p_floats * sizeof(float), stream);
+        prof_memset_async(v_arena, 0, p_floats * sizeof(float), stream);
         VR_HIP(hipStreamSynchronize(stream));
     }
 }

@@ -56,6 +56,34 @@ struct DeviceGuard {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Launch profiler (profile.hip; bench.py's per-kernel-class roofline).  While a handle is profiling (vr_profile_begin), every
+// kernel launched through VR_LAUNCH is bracketed by HIP events ON THE STREAM IT IS LAUNCHED ON and recorded under its own
+// (demangled) kernel name together with the algorithmic FLOPs / HBM bytes noted for it: the executor notes a convolution's
+// figures right before launch_conv (strong note), the launch wrappers of the element-wise kernels note theirs (weak: kept only
+// if nothing is pending).  A note is consumed by the first launch after it.  Off (g_launch_prof == nullptr) the macro is a
+// plain hipLaunchKernelGGL.
+// ---------------------------------------------------------------------------------------------
+struct LaunchProfiler;
+extern thread_local LaunchProfiler* g_launch_prof;
+void prof_note(double flops, double bytes, bool strong = false, const char* tag = nullptr);
+void prof_note_update(double bytes, const char* tag);           // add bytes / tag to the pending strong note
+void prof_note_clear();
+LaunchProfiler* prof_create();
+void prof_destroy(LaunchProfiler* p);
+void prof_collect(LaunchProfiler* p, double* conv_ms, double* conv_flops, double* conv_bytes, int* conv_launches, std::string* report,
+                  bool dump);
+void prof_before(const void* fn, const char* label, hipStream_t st);
+void prof_after(hipStream_t st);
+void prof_memset_async(void* p, int value, size_t bytes, hipStream_t st);      // hipMemsetAsync, recorded as "memset"
+
+#define VR_LAUNCH(kern, grid, block, lds, st, ...)                                                                     \
+    do {                                                                                                               \
+        if (::vr::g_launch_prof) ::vr::prof_before(reinterpret_cast<const void*>(kern), #kern, st);                    \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                                   \
+        if (::vr::g_launch_prof) ::vr::prof_after(st);                                                                 \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
 // Activation tensors in HBM.
 //
 // Layout: [N, C, H, W] fp32, W (time frames) contiguous, arbitrary N/C/H strides so that band

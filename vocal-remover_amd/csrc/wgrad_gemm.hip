@@ -176,11 +176,11 @@ void wgrad_gemm_launch(const WgradArgs& a, hipStream_t st) {
     const int grid = ((a.P + 7) / 8) * 8 * a.nchunks * a.nct;
     if (a.bf16 == 1) {
         ensure_lds_attr(attr_done_bf, reinterpret_cast<const void*>(wgrad_gemm_kernel<true>), WgGemmCfg::LDS_BYTES);
-        hipLaunchKernelGGL(wgrad_gemm_kernel<true>, dim3(grid), dim3(512), WgGemmCfg::LDS_BYTES, st, a, a.tiles_w,
+        VR_LAUNCH(wgrad_gemm_kernel<true>, dim3(grid), dim3(512), WgGemmCfg::LDS_BYTES, st, a, a.tiles_w,
                            (long long)a.in.Hout * a.in.Wout);
     } else {
         ensure_lds_attr(attr_done, reinterpret_cast<const void*>(wgrad_gemm_kernel<false>), WgGemmCfg::LDS_BYTES);
-        hipLaunchKernelGGL(wgrad_gemm_kernel<false>, dim3(grid), dim3(512), WgGemmCfg::LDS_BYTES, st, a, a.tiles_w,
+        VR_LAUNCH(wgrad_gemm_kernel<false>, dim3(grid), dim3(512), WgGemmCfg::LDS_BYTES, st, a, a.tiles_w,
                            (long long)a.in.Hout * a.in.Wout);
     }
     VR_HIP(hipGetLastError());

@@ -464,7 +464,7 @@ static void wg_launch_inst(const WgradArgs& a, hipStream_t st) {
     static std::atomic<unsigned long long> attr_done{0};          // per device (bit = device index)
     ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
     const int grid = ((a.P + 7) / 8) * 8 * a.nchunks * a.nct;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::LDS_BYTES, st, a);
+    VR_LAUNCH(kern, dim3(grid), dim3(256), Cfg::LDS_BYTES, st, a);
     VR_HIP(hipGetLastError());
 }
 
@@ -483,7 +483,7 @@ static void wg_launch_ws_inst(const WgradArgs& a, hipStream_t st) {
     static std::atomic<unsigned long long> attr_done{0};          // per device (bit = device index)
     ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), Ws::LDS_BYTES);
     const int grid = ((a.P + 7) / 8) * 8 * a.nchunks * a.nct;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256 + 64 * NPW), Ws::LDS_BYTES, st, a);
+    VR_LAUNCH(kern, dim3(grid), dim3(256 + 64 * NPW), Ws::LDS_BYTES, st, a);
     VR_HIP(hipGetLastError());
 }
 
@@ -495,7 +495,7 @@ static void wg_launch_ws(const WgradArgs& a, int MB, hipStream_t st) {
 
 static void wgrad_reduce(const WgradArgs& a, float* grad_out, int accumulate, hipStream_t st) {
     const long long n = a.part_stride;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, a.part, a.part_stride,
+    VR_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, a.part, a.part_stride,
                        a.P, grad_out, n, accumulate);
     VR_HIP(hipGetLastError());
 }

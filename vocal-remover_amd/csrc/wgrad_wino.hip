@@ -370,7 +370,7 @@ static void ww_launch(const WgradArgs& a, hipStream_t st) {
     static std::atomic<unsigned long long> attr_done{0};          // per device (bit = device index)
     ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
     const int grid = ((a.P + 7) / 8) * 8 * a.nchunks * a.nct;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), Cfg::LDS_BYTES, st, a);
+    VR_LAUNCH(kern, dim3(grid), dim3(512), Cfg::LDS_BYTES, st, a);
     VR_HIP(hipGetLastError());
 }
 

@@ -97,6 +97,9 @@ def main(argv=None):
     p.add_argument('--output_dir', '-o', type=str, default="")
     args = p.parse_args(argv)
 
+    if args.output_image:
+        print('--output_image: not written by this entry point (spectrogram_to_image + cv2 are outside the MI355X path); run the '
+              "reference's inference.py through vocal-remover_amd/run.py to get the image dumps")
     device = torch.device('cuda:{}'.format(max(args.gpu, 0)))
     model = nets.CascadedNet(args.n_fft, args.hop_length, 32, 128)
     model.load_state_dict(torch.load(args.pretrained_model, map_location='cpu'))

@@ -63,6 +63,7 @@ _SIGNATURES = {
     'vr_profile_end': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
                                       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int),
                                       ctypes.POINTER(ctypes.c_double)]),
+    'vr_profile_report': (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]),
     'vr_debug_conv2d': (ctypes.c_int, [ctypes.c_void_p, c_f32p] + [ctypes.c_int] * 4 + [c_f32p] + [ctypes.c_int] * 6
                         + [c_f32p, ctypes.c_float, c_f32p, c_f32p, c_f32p]),
     'vr_debug_conv2d_backward': (ctypes.c_int, [ctypes.c_void_p, c_f32p] + [ctypes.c_int] * 4 + [c_f32p]

@@ -201,6 +201,10 @@ class CascadedNet(object):
                                                          None, 0))
         elif device.type == 'cpu':
             self._pull()
+            if self._flat is not None and self._handle is not None:
+                import warnings
+                warnings.warn('CascadedNet.to("cpu"): the parameter handed out by parameters() is empty until the model moves back '
+                              'to a GPU (there is no CPU compute path); an optimizer that holds it steps nothing meanwhile')
             self._drop_handle()
             self._device = device
         else:
@@ -209,14 +213,16 @@ class CascadedNet(object):
 
     def _drop_handle(self):
         """Close the native handle.  The flat Parameter / gradient views point into its arenas: detach them first, so that an
-        optimizer that still holds the Parameter steps an EMPTY tensor with no gradient instead of freed device memory."""
+        optimizer that still holds the Parameter never touches freed device memory.  The Parameter OBJECT is kept: the next handle
+        (`.to(cuda:N)`) rebinds its .data / .grad to the new arenas, so an optimizer built from model.parameters() before the move
+        keeps stepping the model, as with nn.Module.to (a torch optimizer's own state tensors do not move -- build it after .to(),
+        as the reference does, train.py:211-218)."""
         if self._handle is None:
             return
         if self._flat is not None:
             self._flat.grad = None
             self._flat.data = torch.empty(0)
-            self._flat._vr_model = None
-        self._flat = self._flat_grad = None
+        self._flat_grad = None
         self._flat_key = None
         self._handle.close()
         self._handle = None
@@ -308,9 +314,14 @@ class CascadedNet(object):
         self._need_handle()
         key = self._handle_gen                       # (not id(handle): CPython reuses ids of closed handles)
         if self._flat_key != key:
-            flat = torch.nn.Parameter(self._arena_tensor(native.lib().vr_param_arena), requires_grad=True)
-            flat._vr_model = self
-            self._flat, self._flat_grad, self._flat_key = flat, self._arena_tensor(native.lib().vr_grad_arena), key
+            arena = self._arena_tensor(native.lib().vr_param_arena)
+            if self._flat is None:
+                self._flat = torch.nn.Parameter(arena, requires_grad=True)
+                self._flat._vr_model = self
+            else:                                    # a new handle after .to(): the SAME Parameter object, rebound
+                self._flat.grad = None
+                self._flat.data = arena
+            self._flat_grad, self._flat_key = self._arena_tensor(native.lib().vr_grad_arena), key
         if self._flat.grad is None or self._flat.grad.data_ptr() != self._flat_grad.data_ptr():
             self._flat.grad = self._flat_grad
         return self._flat
