@@ -277,6 +277,7 @@ def test_b16_train_step_vs_cpu_oracle(vr, full16):
         assert abs(loss - loss_c) < 2e-6, (mode, loss, loss_c)
         e_mask = float((mask.cpu() - mask_c).abs().max())
         rel, bad, dot, n_g, n_c, norm_dev = [], [], 0.0, 0.0, 0.0, 0.0
+        small_a, small_b = [], []
         for k in g_c:
             if k.endswith('dense.0.bias'):
                 assert float(grads[k].abs().max()) < 1e-6, k           # exact gradient 0: a BatchNorm follows the bias
@@ -289,20 +290,24 @@ def test_b16_train_step_vs_cpu_oracle(vr, full16):
                 norm_dev = max(norm_dev, abs(float(a.norm() / (b.norm() + 1e-30)) - 1.0))
                 if e > 6e-2:
                     bad.append('%s %.3e' % (k, e))
-            elif e > 1.0:
+            else:
                 # the 1-element BatchNorm weight / bias of an LSTM squeeze conv: a sum of 0.5 M products of either sign that cancels
                 # to a few per cent of its terms, so the 2-3 % disagreement of two fp32 evaluations upstream shows as tens of per
-                # cent here (measured 0.60 on stg1_low ...conv.1.weight; batch 2 vs fp64: CPU fp32 0.06, GPU 0.15-0.35); sign and
-                # magnitude must hold, the reduction itself is pinned at 1e-4 against fp64 in test_gpu_kernels.py (bn_backward)
-                bad.append('%s %.3e (small tensor)' % (k, e))
+                # cent -- or, where the sum nearly vanishes, as a multiple -- of the value itself (measured 0.60 / 2.3; batch 2 vs
+                # fp64: CPU fp32 0.06, GPU 0.15-0.35).  A relative error of a near-zero scalar says nothing: these tensors are
+                # compared as ONE concatenated vector; the reduction itself is pinned at 1e-4 against fp64 in test_gpu_kernels.py
+                small_a.append(a.reshape(-1)); small_b.append(b.reshape(-1))
         rel.sort(reverse=True)
         med = float(np.median([r[0] for r in rel]))
         cos = dot / (n_g * n_c) ** 0.5
         print('mfma_mode %d, batch 16 vs fp32 CPU oracle: loss %.8f / %.8f; mask max-abs %.2e; gradient rel-L2 median %.2e, worst %s '
               '%.2e; per-tensor norm deviation max %.2e; global cosine %.6f' % (mode, loss, loss_c, e_mask, med, rel[0][1], rel[0][0],
                                                                                 norm_dev, cos))
+        sa, sb = torch.cat(small_a), torch.cat(small_b)
+        e_small = float((sa - sb).norm() / sb.norm())
+        print('            the %d tensors with < 16 elements as one vector: rel-L2 %.2e' % (len(small_a), e_small))
         assert not bad, '\n'.join(bad)
-        assert med < 3e-2 and cos > 0.999 and norm_dev < 2e-2 and e_mask < 5e-4
+        assert med < 3e-2 and cos > 0.999 and norm_dev < 2e-2 and e_mask < 5e-4 and e_small < 0.25
         for k in sd32:
             if k.endswith('running_mean') or k.endswith('running_var'):
                 scale = float(sd32[k].abs().max()) + 1e-6

@@ -17,6 +17,10 @@ __device__ __forceinline__ i32x4 make_rsrc(const float* base, unsigned bytes) {
     return r;
 }
 
+// A descriptor fresh from v_readfirstlane must sit 5 wait states before a buffer_* instruction reads it, and hipcc neither sees
+// inside an asm string nor pads in front of one: settle it explicitly (the operand pins the readfirstlanes in front of the nop).
+__device__ __forceinline__ void settle_rsrc(i32x4& r) { asm volatile("s_nop 4" : "+s"(r)); }
+
 // One 64-lane LDS-DMA: lane l copies 16 B from rsrc.base + voff[l] to LDS byte lds_base + 16*l.
 // Inline asm on purpose: the compiler does not track it, so it never inserts a vmcnt(0) in front of
 // unrelated LDS reads; the caller waits with dma_wait() before the data is consumed.

@@ -64,6 +64,12 @@ struct Conv {
     float* wino = nullptr;          // eval: Winograd-transformed weights [Cin][16][CoutPad] (3x3 stride-1 layers)
     void* wino6 = nullptr;          // mfma_mode 2: the same as three bf16 planes (conv_wino.hip: wino_weights6_kernel)
     void* x3w = nullptr;            // mfma_mode 2: the direct weights as three bf16 planes (conv_x3.hip: x3_weights_kernel)
+    // eval, mfma_mode 2 (conv_x3p.hip): the same for the PADDED channel order of the layer's sources (every source of the virtual
+    // concat occupies whole 8-channel groups); the segmentation is recorded by the planning dry run, the table is built after it
+    void* x3p = nullptr;
+    int x3p_seg[3] = {0, 0, 0};
+    int x3p_nchunk = 0;
+    bool x3p_built = false;
 };
 
 struct LSTMMod {
@@ -202,6 +208,10 @@ private:
     X3Batch xb_fwd, xb_bwd;
     void run_x3_batch(X3Batch& b, std::vector<X3WDesc>& descs);
     void refresh_wino(bool with_dgrad);
+    char* x3p_arena = nullptr;                           // eval: plane-order weight tables of the 3x3 stride-1 layers (conv_x3p.hip)
+    X3pWDesc* x3p_descs = nullptr; size_t x3p_descs_cap = 0;
+    void refresh_x3p();                                  // builds the tables whose segmentation is known and that are stale
+    bool x3p_on() const { return !training && mfma_mode == 2 && x3p_enabled(); }
     // batched refresh: descriptor tables (host copy + device copy, re-uploaded only when a pointer changed)
     struct WinoBatch { std::vector<WinoWDesc> host; WinoWDesc* dev = nullptr; long long max_elems = 0; };
     WinoBatch wb_fwd, wb_bwd, wb_fwd6, wb_bwd6;
@@ -299,8 +309,10 @@ public:
     void* wire_buf = nullptr;                            // bf16 copy of the gradient bucket (wire_dtype 1)
 private:
     void build_fwd_args(Conv& L, const std::vector<SrcSpec>& srcs, int N, bool batch_as_h, ConvArgs& a);
+    bool run_conv_x3p(Conv& L, const std::vector<SrcSpec>& srcs, int N, const Tensor* out_view, const float* bias, int fmt, Tensor* out);
+    // fmt (eval, conv_x3p.hip launches only): 0 = fp32 output, 2 = fp32 AND bf16 planes (tensors that feed 3x3 stride-1 convs)
     Tensor run_conv(Conv& L, const std::vector<SrcSpec>& srcs, int N, const Tensor* out_view, const float* bias,
-                    bool batch_as_h);
+                    bool batch_as_h, int fmt = 0);
     template <class F> void for_each_conv(F&& f);
     Tensor run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, const Tensor* out_view);
     Tensor run_lstm(LSTMMod& M, const Tensor& h);

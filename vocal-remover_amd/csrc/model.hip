@@ -332,7 +332,42 @@ void Model::fold_eval_affines() {
     for (BN* b : bn_list) maxC = std::max(maxC, std::max(b->C, b->bcast));
     launch_bn_fold_eval(d_fold, (int)bn_list.size(), maxC, 1e-5f, stream);
     refresh_wino(false);        // the weights may have changed too (set_param / Adam)
+    for (Conv* L : wino_list) L->x3p_built = false;
+    refresh_x3p();
     affine_dirty = false;
+}
+
+// Plane-order weight tables (conv_x3p.hip) of the layers whose source segmentation the planning dry run has recorded.
+void Model::refresh_x3p() {
+    if (!x3p_on()) return;
+    if (!x3p_arena) {
+        size_t total = 0;
+        for (Conv* L : wino_list) total += x3p_weights_bytes((L->Cin + 7) / 8 + 2, L->CoutPad);
+        VR_HIP(hipMalloc(reinterpret_cast<void**>(&x3p_arena), total ? total : 16));
+        size_t off = 0;
+        for (Conv* L : wino_list) { L->x3p = x3p_arena + off; off += x3p_weights_bytes((L->Cin + 7) / 8 + 2, L->CoutPad); }
+    }
+    std::vector<X3pWDesc> d;
+    long long max_elems = 0;
+    for (Conv* L : wino_list) {
+        if (L->x3p_nchunk == 0 || L->x3p_built) continue;
+        X3pWDesc e{};
+        e.w = L->w->dev; e.o = L->x3p; e.nchunk = L->x3p_nchunk; e.CoutPad = L->CoutPad;
+        for (int i = 0; i < 3; ++i) e.seg[i] = L->x3p_seg[i];
+        d.push_back(e);
+        max_elems = std::max(max_elems, (long long)L->x3p_nchunk * 8 * 9 * L->CoutPad);
+        L->x3p_built = true;
+    }
+    if (d.empty()) return;
+    if (d.size() > x3p_descs_cap) {
+        VR_HIP(hipStreamSynchronize(stream));
+        if (x3p_descs) VR_HIP(hipFree(x3p_descs));
+        x3p_descs_cap = wino_list.size();
+        VR_HIP(hipMalloc(reinterpret_cast<void**>(&x3p_descs), x3p_descs_cap * sizeof(X3pWDesc)));
+    }
+    VR_HIP(hipMemcpyAsync(x3p_descs, d.data(), d.size() * sizeof(X3pWDesc), hipMemcpyHostToDevice, stream));
+    VR_HIP(hipStreamSynchronize(stream));                 // (d is a local; rare: once per weight change)
+    launch_x3p_weights(x3p_descs, (int)d.size(), max_elems, stream);
 }
 
 void Model::set_option(const std::string& name, int value) {
@@ -648,8 +683,87 @@ void Model::build_fwd_args(Conv& L, const std::vector<SrcSpec>& srcs, int N, boo
     a.pad_h = L.pad_h; a.pad_w = L.pad_w;
 }
 
+// Eval, mfma_mode 2: a 3x3 stride-1 launch over bf16-plane sources (conv_x3p.hip).  Sources that do not carry planes yet are
+// converted (to_planes_kernel: thin tensors -- the network input, stage outputs, the LSTM branch, stride-2 conv outputs).
+bool Model::run_conv_x3p(Conv& L, const std::vector<SrcSpec>& srcs, int N, const Tensor* out_view, const float* bias, int fmt, Tensor* out) {
+    if (!x3p_on() || !(L.KS == 3 && L.stride == 1 && L.dh == 1 && L.dw == 1 && L.pad_h == 1 && L.pad_w == 1)) return false;
+    if (srcs.empty() || srcs.size() > 3) return false;
+    int H = -1, W = -1, ctot = 0;
+    for (const SrcSpec& sp : srcs) {
+        const Tensor& t = sp.t;
+        if (sp.up || sp.bcastH || t.aff0 || t.aff1 || t.post || t.slope != 1.f) return false;     // plain tensors only (eval)
+        if (H < 0) { H = t.H; W = t.W; }
+        VR_CHECK(t.H == H && t.W == W, -5, "h1_shape[3] must be greater than h2_shape[3] (decoder skip/upsample size mismatch in " + L.name + ")");
+        ctot += t.C;
+    }
+    if (W < 32) return false;
+    VR_CHECK(ctot == L.Cin, -2, "conv " + L.name + ": channel count mismatch");
+    bool found = false;
+    for (Conv* q : wino_list) found = found || q == &L;
+    if (!found) return false;
+    X3pArgs a{};
+    a.nsrc = (int)srcs.size();
+    int seg[3] = {0, 0, 0}, nchunk = 0;
+    for (int i = 0; i < a.nsrc; ++i) {
+        const Tensor& t = srcs[i].t;
+        const int G = (t.C + 7) / 8;
+        const size_t bytes = (size_t)t.N * G * 3 * H * W * 16;
+        const char* pl = t.pl;
+        if (!pl) {
+            VR_CHECK(t.p != nullptr, -2, "conv " + L.name + ": source without values");
+            char* buf = static_cast<char*>(ws.alloc(bytes));
+            if (!dry) launch_to_planes(t, buf, stream);
+            pl = buf;
+        }
+        a.src[i] = X3pSrc{pl, (long long)G * 3 * H * W * 16, (long long)3 * H * W * 16, G};
+        seg[i] = t.C; nchunk += G;
+    }
+    if (L.x3p_nchunk != nchunk || L.x3p_seg[0] != seg[0] || L.x3p_seg[1] != seg[1] || L.x3p_seg[2] != seg[2]) {
+        VR_CHECK(dry, -2, "conv " + L.name + ": plane-order weight table does not match the sources (no planning pass ran)");
+        L.x3p_nchunk = nchunk; L.x3p_seg[0] = seg[0]; L.x3p_seg[1] = seg[1]; L.x3p_seg[2] = seg[2];
+        L.x3p_built = false;
+    }
+    a.nchunk = nchunk;
+    a.w = L.x3p; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
+    a.bias = bias;
+    a.epi = L.bn ? L.bn->affine : nullptr;
+    a.slope = L.bn ? L.slope : 1.f;
+    a.N = N; a.H = H; a.W = W;
+    Tensor o;
+    o.N = N; o.C = L.Cout; o.H = H; o.W = W; o.slope = 1.f;
+    if (out_view) {
+        VR_CHECK(out_view->H == H && out_view->W == W && out_view->C == L.Cout, -2, "conv " + L.name + ": output view shape mismatch");
+        o.p = out_view->p; o.sN = out_view->sN; o.sC = out_view->sC; o.sH = out_view->sH;
+    } else {
+        o.p = ws.allocf((size_t)N * L.Cout * H * W);
+        o.sH = W; o.sC = (long long)H * W; o.sN = o.sC * L.Cout;
+    }
+    a.out = o.p; a.oN = o.sN; a.oC = o.sC; a.oH = o.sH;
+    if (fmt == 2) {
+        char* pl = static_cast<char*>(ws.alloc((size_t)N * ((L.Cout + 7) / 8) * 3 * H * W * 16));
+        a.opl = pl; o.pl = pl;
+    }
+    if (!dry) {
+        VR_CHECK(L.x3p_built && L.x3p != nullptr, -2, "conv " + L.name + ": plane-order weight table not built");
+        record_begin(0, 2.0 * N * (double)H * W * (double)L.Cout * L.Cin * 9);
+        if (profiling) {
+            char tag[160];
+            snprintf(tag, sizeof tag, "%s k3 s1 d1 ci%d co%d %dx%dx%d (planes)", L.name.c_str(), L.Cin, L.Cout, N, H, W);
+            record_note(4.0 * ((double)N * L.Cin * H * W + (double)N * L.Cout * H * W + (double)L.Cin * 9 * L.Cout), tag);
+        }
+        x3p_launch(a, stream);
+        record_end();
+    }
+    *out = o;
+    return true;
+}
+
 Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs_in, int N, const Tensor* out_view, const float* bias,
-                       bool batch_as_h) {
+                       bool batch_as_h, int fmt) {
+    if (!training && !batch_as_h) {
+        Tensor o;
+        if (run_conv_x3p(L, srcs_in, N, out_view, bias, fmt, &o)) return o;
+    }
     // Training: give the conv plain inputs (one element-wise / upsample pass per source) -- the forward conv
     // then takes the LDS-DMA kernel and the weight gradient re-reads the same buffers without arithmetic.
     std::vector<SrcSpec> srcs = srcs_in;
@@ -846,6 +960,19 @@ Model::SrcSpec Model::upsampled(const Tensor& t) {
     // layers read the LOW-resolution tensor (a quarter of the bytes) and nothing is materialised.  Measured per layer (tools/
     // x3_proto.hip): it pays from 512 x 128 output pixels on (dec1, stage-3 dec2); below, the interpolation VALU of the many-channel
     // layers costs more than the HBM-bound upsample pass.
+    // Plane path (conv_x3p.hip): the x2 result is written as bf16 planes by an HBM-bound pass -- its interpolation and split VALU
+    // cost nothing there, and the consuming conv pulls it by LDS-DMA.  Every decoder conv is 3x3 stride-1: it takes the plane kernel
+    // from 32 output columns on.
+    if (x3p_on() && 2 * t.W >= 32 && !t.aff0 && !t.aff1 && !t.post && t.slope == 1.f && t.p) {
+        Tensor u;
+        u.N = t.N; u.C = t.C; u.H = 2 * t.H; u.W = 2 * t.W;
+        u.sH = u.W; u.sC = (long long)u.H * u.W; u.sN = u.sC * u.C; u.slope = 1.f;
+        u.p = nullptr;
+        char* buf = static_cast<char*>(ws.alloc((size_t)u.N * ((u.C + 7) / 8) * 3 * u.H * u.W * 16));
+        if (!dry) launch_upsample2x_planes(t, buf, stream);
+        u.pl = buf;
+        return SrcSpec{u};
+    }
     static const bool fuse_on = !(getenv("VR_X3_FUSE_UP") && atoi(getenv("VR_X3_FUSE_UP")) == 0);
     static const bool x3_on = !(getenv("VR_CONV_X3") && atoi(getenv("VR_CONV_X3")) == 0);
     if (fuse_on && x3_on && mfma_mode == 2 && 4LL * t.H * t.W >= 65536 && 2 * t.W >= 32 && !t.aff0 && !t.aff1 && !t.post && t.slope == 1.f) {
@@ -865,11 +992,13 @@ Model::SrcSpec Model::upsampled(const Tensor& t) {
 Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, const Tensor* out_view) {
     const std::string& p = B.prefix;
     Tensor e[5];
-    e[0] = run_conv(B.enc1, in, N, nullptr, nullptr, false);
+    // e1..e4 feed a stride-2 conv (fp32) AND, as skip connections, a decoder conv (planes on the plane path)
+    const int skip_fmt = x3p_on() ? 2 : 0;
+    e[0] = run_conv(B.enc1, in, N, nullptr, nullptr, false, skip_fmt);
     tap(p + ".e1", e[0]);
     for (int i = 0; i < 4; ++i) {
         Tensor t = run_conv(B.enc_a[i], {SrcSpec{e[i]}}, N, nullptr, nullptr, false);
-        e[i + 1] = run_conv(B.enc_b[i], {SrcSpec{t}}, N, nullptr, nullptr, false);
+        e[i + 1] = run_conv(B.enc_b[i], {SrcSpec{t}}, N, nullptr, nullptr, false, i < 3 ? skip_fmt : 0);
         tap(p + ".e" + std::to_string(i + 2), e[i + 1]);
     }
     // layers.ASPPModule.forward (lib/layers.py:92-105)
@@ -1040,6 +1169,7 @@ void Model::plan_and_reserve(int B, int T, size_t extra_bytes) {
     ws = saved;
     ensure_ws(need);
     ws.reset();
+    refresh_x3p();                               // (segmentations the dry run has just recorded)
 }
 
 static void check_T(int T, int offset, int mode) {

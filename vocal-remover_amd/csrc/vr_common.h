@@ -110,6 +110,8 @@ struct Tensor {
     float slope = 1.f;
     const float* post = nullptr;   // [N][C] post-activation multiplier (Dropout2d), or null
     float* g = nullptr;            // training: gradient w.r.t. the value consumers see (same strides as p)
+    const char* pl = nullptr;      // eval, mfma_mode 2: the same values as three bf16 planes, dense [N][ceil(C/8)][3][H][W] of 16-byte
+                                   // units (8 channels of one pixel in one plane; conv_x3p.hip) -- what the 3x3 stride-1 convs read
 };
 
 // One input of a (virtually concatenated) convolution.
