@@ -115,3 +115,31 @@ def test_conv_planes_is_fp32_exact_on_special_values(handle):
         print('scales %s x %g: %.2e (torch CPU fp32 %.2e)' % (scale_x, scale_w, e_gpu, e_cpu))
         assert np.isfinite(got).all() and e_gpu <= 3 * e_cpu + 2e-7
         assert np.array_equal(back, got)
+
+
+def test_full_net_on_the_plane_path_vs_oracle_and_default_path(vr):
+    """vr_set_option('conv_x3p', 1): the whole eval executor with plane tensors (skip connections written as fp32 + planes by the conv
+    epilogue, decoder upsamples written as planes, thin tensors converted) against the CPU oracle under the bars of the default path
+    (mask max 1e-4 / mean 1e-5) and against the default path itself."""
+    from oracle import cascaded_net, weights
+    sd = weights.make_state_dict(1234)
+    model = vr.nets.CascadedNet(2048, 1024, 32, 128)
+    model.load_state_dict(sd)
+    model.to(torch.device('cuda:0')).eval()
+    x = torch.rand(2, 2, 1025, 256, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        want = cascaded_net.predict_mask(x, sd)
+    base = model.predict_mask(x.to('cuda:0')).cpu()
+    try:
+        model.set_option('conv_x3p', 1)
+        got = model.predict_mask(x.to('cuda:0')).cpu()
+        again = model.predict_mask(x.to('cuda:0')).cpu()
+    finally:
+        model.set_option('conv_x3p', -1)
+    d = (got - want).abs()
+    print('plane path: mask max %.2e mean %.2e vs oracle; max %.2e vs the default path' % (float(d.max()), float(d.mean()), float((got - base).abs().max())))
+    assert float(d.max()) < 1e-4 and float(d.mean()) < 1e-5
+    assert float((got - base).abs().max()) < 2e-5
+    assert torch.equal(got, again)
+    after = model.predict_mask(x.to('cuda:0')).cpu()
+    assert torch.equal(after, base)                    # switching back restores the default executor exactly

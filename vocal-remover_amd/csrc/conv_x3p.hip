@@ -406,7 +406,7 @@ void launch_planes_to_f32(const char* pl, float* out, int N, int C, int H, int W
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
 bool x3p_enabled() {
-    static const bool on = [] { const char* e = getenv("VR_CONV_X3P"); return !e || atoi(e) != 0; }();
+    static const bool on = [] { const char* e = getenv("VR_CONV_X3P"); return e && atoi(e) != 0; }();      // default OFF (see the header)
     return on;
 }
 

@@ -211,7 +211,10 @@ private:
     char* x3p_arena = nullptr;                           // eval: plane-order weight tables of the 3x3 stride-1 layers (conv_x3p.hip)
     X3pWDesc* x3p_descs = nullptr; size_t x3p_descs_cap = 0;
     void refresh_x3p();                                  // builds the tables whose segmentation is known and that are stale
-    bool x3p_on() const { return !training && mfma_mode == 2 && x3p_enabled(); }
+    // vr_set_option("conv_x3p"): -1 = the default (VR_CONV_X3P, else OFF: measured no faster than conv_x3.hip and its producers cost
+    // more than the split pass they replace -- DESIGN.md section 3), 0 off, 1 on
+    int x3p_opt = -1;
+    bool x3p_on() const { return !training && mfma_mode == 2 && (x3p_opt < 0 ? x3p_enabled() : x3p_opt != 0); }
     // batched refresh: descriptor tables (host copy + device copy, re-uploaded only when a pointer changed)
     struct WinoBatch { std::vector<WinoWDesc> host; WinoWDesc* dev = nullptr; long long max_elems = 0; };
     WinoBatch wb_fwd, wb_bwd, wb_fwd6, wb_bwd6;

@@ -380,6 +380,7 @@ void Model::set_option(const std::string& name, int value) {
         if (value < -1 || value > 2) throw Error(-2, "mfma_mode: 0, 1, 2 or -1 (default)");
         mfma_mode = value < 0 ? default_mfma_mode : value; affine_dirty = true;   // (the next eval forward refreshes the derived weight copies)
     }
+    else if (name == "conv_x3p") { x3p_opt = value < 0 ? -1 : (value != 0); affine_dirty = true; }   // eval: 3x3 stride-1 convs over bf16-plane tensors (conv_x3p.hip)
     else if (name == "adam_reset") reset_adam_state();      // a freshly constructed torch.optim.Adam has no moments
     else throw Error(-2, "unknown option: " + name);
 }
