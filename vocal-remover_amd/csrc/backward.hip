@@ -179,7 +179,7 @@ void launch_bn_bwd(const BnBwdArgs& a, hipStream_t st) {
 // Transposed bilinear x2 (align_corners=True): G_lo += U^T D_hi, gather form (no atomics).
 // ---------------------------------------------------------------------------------------------------
 __global__ void upsample_bwd_kernel(const float* __restrict__ dhi, int N, int C, int H, int W, float rh, float rw,
-                                    float* __restrict__ glo, long long gN, long long gC, long long gH) {
+                                    float* __restrict__ glo, long long gN, long long gC, long long gH, int accumulate) {
     const long long total = (long long)N * C * H * W;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
@@ -230,7 +230,8 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ dhi, int N, int C,
             if (ww[dw] != 0.f) r = fmaf(ww[dw], row[dw], r);
         acc = fmaf(wh[dh], r, acc);
     }
-    glo[(long long)n * gN + (long long)c * gC + (long long)i * gH + j] += acc;
+    float* const gq = glo + (long long)n * gN + (long long)c * gC + (long long)i * gH + j;
+    *gq = accumulate ? *gq + acc : acc;
 }
 
 // LDS-tiled form for the large tensors: one workgroup = an 8 x 32 tile of low-resolution outputs of one (n, c) plane;
@@ -240,7 +241,7 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ dhi, int N, int C,
 __global__ __launch_bounds__(256) void upsample_bwd_tiled_kernel(const float* __restrict__ dhi, int C, int H, int W, float rh,
                                                                  float rw, int tiles_w, int tiles_per_plane,
                                                                  float* __restrict__ glo, long long gN, long long gC,
-                                                                 long long gH) {
+                                                                 long long gH, int accumulate) {
     constexpr int TI = 8, TJ = 32, PH = 2 * TI + 3, PW = 2 * TJ + 3, PP = PW + 1;
     __shared__ float patch[PH * PP];
     const int plane = blockIdx.x / tiles_per_plane;          // n * C + c
@@ -310,27 +311,28 @@ __global__ __launch_bounds__(256) void upsample_bwd_tiled_kernel(const float* __
         acc = fmaf(wh[dh], r, acc);
     }
     const int n = plane / C, c = plane - n * C;
-    glo[(long long)n * gN + (long long)c * gC + (long long)i * gH + j] += acc;
+    float* const gq = glo + (long long)n * gN + (long long)c * gC + (long long)i * gH + j;
+    *gq = accumulate ? *gq + acc : acc;
 }
 
 void launch_upsample_bwd(const float* dhi, int N, int C, int H, int W, float* glo, long long gN, long long gC,
-                         long long gH, hipStream_t st) {
+                         long long gH, int accumulate, hipStream_t st) {
     const long long total = (long long)N * C * H * W;
     const float rh = (float)(H - 1) / (float)(2 * H - 1), rw = (float)(W - 1) / (float)(2 * W - 1);
     static const bool tiled = !getenv("VR_NO_UPBWD_TILED");
-    prof_note(0.0, 4.0 * 6.0 * (double)total);               // reads the 4x larger gradient, read-modify-writes the low-resolution one
+    prof_note(0.0, 4.0 * (accumulate ? 6.0 : 5.0) * (double)total);   // reads the 4x larger gradient, writes (accumulating: read-modify-writes) the low-resolution one
     if (tiled && W >= 16 && H >= 4) {
         const int tiles_w = (W + 31) / 32, tiles_h = (H + 7) / 8;
         const long long blocks = (long long)N * C * tiles_h * tiles_w;
         if (blocks < 0x7FFFFFFFLL) {
             VR_LAUNCH(upsample_bwd_tiled_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dhi, C, H, W, rh, rw, tiles_w,
-                               tiles_h * tiles_w, glo, gN, gC, gH);
+                               tiles_h * tiles_w, glo, gN, gC, gH, accumulate);
             VR_HIP(hipGetLastError());
             return;
         }
     }
     VR_LAUNCH(upsample_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dhi, N, C, H, W, rh, rw,
-                       glo, gN, gC, gH);
+                       glo, gN, gC, gH, accumulate);
     VR_HIP(hipGetLastError());
 }
 
@@ -354,7 +356,7 @@ void launch_sum_h(const float* d, int N, int C, int H, int W, float* out, hipStr
 
 // g[n][c][h][w] += gp[n][c][w] / H     (backward of AdaptiveAvgPool2d((1,None)), lib/layers.py:72)
 __global__ void avgpool_bwd_kernel(const float* __restrict__ gp, float* __restrict__ g, int N, int C, int H, int W,
-                                   long long sN, long long sC, long long sH) {
+                                   long long sN, long long sC, long long sH, int accumulate) {
     const long long total = (long long)N * C * H * W;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
@@ -363,13 +365,15 @@ __global__ void avgpool_bwd_kernel(const float* __restrict__ gp, float* __restri
     const int h = (int)(t % H); t /= H;
     const int c = (int)(t % C);
     const int n = (int)(t / C);
-    g[(long long)n * sN + (long long)c * sC + (long long)h * sH + w] += gp[((long long)n * C + c) * W + w] / (float)H;
+    float* const q = g + (long long)n * sN + (long long)c * sC + (long long)h * sH + w;
+    const float v = gp[((long long)n * C + c) * W + w] / (float)H;
+    *q = accumulate ? *q + v : v;
 }
 void launch_avgpool_bwd(const float* gp, float* g, int N, int C, int H, int W, long long sN, long long sC, long long sH,
-                        hipStream_t st) {
+                        int accumulate, hipStream_t st) {
     const long long total = (long long)N * C * H * W;
     VR_LAUNCH(avgpool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gp, g, N, C, H, W, sN,
-                       sC, sH);
+                       sC, sH, accumulate);
     VR_HIP(hipGetLastError());
 }
 

@@ -167,7 +167,7 @@ void Model::debug_kernel(const std::string& name, const int64_t* dims, int ndims
         const size_t n = (size_t)N * C * H * W;
         DevBuf x(in[0], n), dhi(in[1], 4 * n), up(4 * n), glo(n);
         launch_upsample2x(dense(x.p, N, C, H, W), up.p, st);
-        launch_upsample_bwd(dhi.p, N, C, H, W, glo.p, (long long)C * H * W, (long long)H * W, W, st);
+        launch_upsample_bwd(dhi.p, N, C, H, W, glo.p, (long long)C * H * W, (long long)H * W, W, 1, st);
         VR_HIP(hipStreamSynchronize(st));
         up.download(out[0]); glo.download(out[1]);
     } else if (name == "pool") {
@@ -176,7 +176,7 @@ void Model::debug_kernel(const std::string& name, const int64_t* dims, int ndims
         const size_t n = (size_t)N * C * H * W, m = (size_t)N * C * W;
         DevBuf x(in[0], n), gp(in[1], m), d(in[2], n), pooled(m), g(n), sumh(m);
         launch_avgpool_h(dense(x.p, N, C, H, W), pooled.p, st);
-        launch_avgpool_bwd(gp.p, g.p, N, C, H, W, (long long)C * H * W, (long long)H * W, W, st);
+        launch_avgpool_bwd(gp.p, g.p, N, C, H, W, (long long)C * H * W, (long long)H * W, W, 1, st);
         launch_sum_h(d.p, N, C, H, W, sumh.p, st);
         VR_HIP(hipStreamSynchronize(st));
         pooled.download(out[0]); g.download(out[1]); sumh.download(out[2]);

@@ -132,10 +132,10 @@ int bn_bwd_chunks(const BnBwdArgs& a);
 void launch_bn_bwd(const BnBwdArgs& a, hipStream_t st);
 
 void launch_upsample_bwd(const float* dhi, int N, int C, int H, int W, float* glo, long long gN, long long gC,
-                         long long gH, hipStream_t st);
+                         long long gH, int accumulate, hipStream_t st);
 void launch_sum_h(const float* d, int N, int C, int H, int W, float* out, hipStream_t st);
 void launch_avgpool_bwd(const float* gp, float* g, int N, int C, int H, int W, long long sN, long long sC, long long sH,
-                        hipStream_t st);
+                        int accumulate, hipStream_t st);
 void launch_thin_dgrad(const Tensor& x, int CO, const float* w, const float* dz, float* g, int accumulate, hipStream_t st);
 int thin_wgrad_blocks(const Tensor& x);
 void launch_thin_wgrad(const Tensor& x, int CO, const float* dz, float* part, float* dw, int accumulate, hipStream_t st);

@@ -260,7 +260,17 @@ private:
         int chain = 0;                         // 1: high-band chain of stages 1-2 (independent of the low-band chain)
     };
     std::vector<TapeRec> tape;
-    Arena gs;                                            // gradients of activations (zeroed per step)
+    Arena gs;                                            // gradients of activations
+    // First writer stores (round 4): the gradient buffer of a conv output is owned by that tensor alone -- every consumer's backward
+    // addresses the whole tensor -- so the first backward writer STORES and the later ones accumulate: no zero fill, and the first
+    // data-gradient epilogue writes instead of read-modify-writing zeros.  Buffers that are written through partial views (the
+    // stage outputs aux1 / aux2: full tensor by stage 3, band halves by stage 2) or by kernels that only accumulate (pooled / LSTM
+    // internals) stay zero-initialised: their byte ranges inside `gs` are recorded by the planning dry run (gs_zero).
+    std::vector<std::pair<size_t, size_t>> gs_zero, gs_zero_plan;      // (offset, bytes); _plan = the dry run's list, what gets cleared
+    std::map<const float*, bool> g_fresh;                // plain buffers of this forward: true until their first backward writer
+    float* galloc(size_t n, bool plain);
+    bool g_first(const float* g);                        // true exactly once per plain buffer: that writer must store, not accumulate
+    void clear_gs_zero_ranges(hipStream_t st);
     float* g_arena = nullptr;                            // gradients of parameters (mirrors p_arena)
     float* m_arena = nullptr; float* v_arena = nullptr;  // Adam moments
     float* wt_arena = nullptr; size_t wt_floats = 0;     // flipped/transposed conv weights for dgrad

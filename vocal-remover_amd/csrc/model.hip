@@ -592,6 +592,36 @@ void Model::profile_end(double* conv_ms, double* conv_flops, double* conv_bytes,
     launch_prof = nullptr;
 }
 
+float* Model::galloc(size_t n, bool plain) {
+    const size_t off = (gs.off + 255) & ~size_t(255);            // (Arena::alloc's own rounding)
+    float* p = gs.allocf(n);
+    if (!plain) gs_zero.push_back({off, n * sizeof(float)});
+    else if (!dry) g_fresh[p] = true;
+    return p;
+}
+
+bool Model::g_first(const float* g) {
+    auto it = g_fresh.find(g);
+    if (it == g_fresh.end() || !it->second) return false;
+    it->second = false;
+    return true;
+}
+
+// zero the buffers of `gs` that need it (ranges recorded by the planning dry run; adjacent ones merged)
+void Model::clear_gs_zero_ranges(hipStream_t st) {
+    size_t i = 0;
+    while (i < gs_zero_plan.size()) {
+        size_t b = gs_zero_plan[i].first, e = b + gs_zero_plan[i].second;
+        size_t j = i + 1;
+        while (j < gs_zero_plan.size() && gs_zero_plan[j].first <= ((e + 255) & ~size_t(255))) {
+            e = std::max(e, gs_zero_plan[j].first + gs_zero_plan[j].second);
+            ++j;
+        }
+        prof_memset_async(gs.base + b, 0, e - b, st);
+        i = j;
+    }
+}
+
 void Model::tap(const std::string& name, const Tensor& t) {
     if (record_taps && !dry) taps[name] = t;
 }
@@ -828,7 +858,7 @@ Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs_in, int N, cons
         if (out_view) { o.p = out_view->p; o.g = out_view->g; o.sN = out_view->sN; o.sC = out_view->sC; o.sH = out_view->sH; }
         else {
             o.p = ws.allocf((size_t)N * L.Cout * a.Wout); o.sN = (long long)L.Cout * a.Wout; o.sC = a.Wout; o.sH = a.Wout;
-            if (taping()) o.g = gs.allocf((size_t)N * L.Cout * a.Wout);
+            if (taping()) o.g = galloc((size_t)N * L.Cout * a.Wout, false);      // (written through the batch-as-rows view: keep it zeroed)
         }
         a.dst[0] = ConvDst{o.p, 0, o.sC, o.sN, 0};
     } else {
@@ -839,7 +869,7 @@ Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs_in, int N, cons
         } else {
             o.p = ws.allocf((size_t)N * L.Cout * a.Hout * a.Wout);
             o.sH = a.Wout; o.sC = (long long)a.Hout * a.Wout; o.sN = o.sC * L.Cout;
-            if (taping()) o.g = gs.allocf((size_t)N * L.Cout * a.Hout * a.Wout);
+            if (taping()) o.g = galloc((size_t)N * L.Cout * a.Hout * a.Wout, true);
         }
         a.dst[0] = ConvDst{o.p, o.sN, o.sC, o.sH, 0};
     }
@@ -911,7 +941,7 @@ Tensor Model::run_lstm(LSTMMod& M, const Tensor& h) {
     if (training) { zt.aff0 = M.squeeze.bn->affine; zt.slope = 0.f; }
     else zt.slope = 1.f;
     if (taping()) {
-        zt.g = gs.allocf((size_t)N * nb * nf);
+        zt.g = galloc((size_t)N * nb * nf, false);
         TapeRec r;
         r.kind = TK_SQUEEZE; r.M = &M; r.srcs = {SrcSpec{h}}; r.N = N;
         r.out = zt;                      // as a 1-channel image [N,1,nb,nf] for its own BatchNorm backward
@@ -932,7 +962,7 @@ Tensor Model::run_lstm(LSTMMod& M, const Tensor& h) {
     ht.p = hc; ht.N = N; ht.C = 2 * M.hid; ht.H = 1; ht.W = nf;
     ht.sN = (long long)2 * M.hid * nf; ht.sC = nf; ht.sH = nf; ht.slope = 1.f;
     if (taping()) {
-        ht.g = gs.allocf((size_t)N * 2 * M.hid * nf);
+        ht.g = galloc((size_t)N * 2 * M.hid * nf, false);
         TapeRec r;
         r.kind = TK_LSTM; r.M = &M; r.N = N; r.out = ht; r.aux = gx; r.save = save;
         tape.push_back(std::move(r));
@@ -1011,7 +1041,7 @@ Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, co
     pt.p = pooled; pt.N = N; pt.C = C8; pt.H = 1; pt.W = x5.W;
     pt.sN = (long long)C8 * x5.W; pt.sC = x5.W; pt.sH = x5.W; pt.slope = 1.f;
     if (taping()) {
-        pt.g = gs.allocf((size_t)N * C8 * x5.W);
+        pt.g = galloc((size_t)N * C8 * x5.W, false);
         TapeRec r;
         r.kind = TK_AVGPOOL; r.srcs = {SrcSpec{x5}}; r.out = pt; r.N = N;
         tape.push_back(std::move(r));
@@ -1022,7 +1052,7 @@ Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, co
     cat4.N = N; cat4.C = 4 * C8; cat4.H = x5.H; cat4.W = x5.W;
     cat4.sH = x5.W; cat4.sC = (long long)x5.H * x5.W; cat4.sN = cat4.sC * cat4.C;
     cat4.p = ws.allocf((size_t)N * cat4.C * x5.H * x5.W);
-    if (taping()) cat4.g = gs.allocf((size_t)N * cat4.C * x5.H * x5.W);
+    if (taping()) cat4.g = galloc((size_t)N * cat4.C * x5.H * x5.W, false);
     if (training) { cat4.aff0 = B.aspp_aff; cat4.slope = 0.f; }      // eval: the branch convs store final activations
     Conv* branch[4] = {&B.aspp_c2, &B.aspp_d[0], &B.aspp_d[1], &B.aspp_d[2]};
     // Eval, stage 3: the four branch convs are independent and each fills < 256 CUs at 1/16 resolution --
@@ -1097,7 +1127,7 @@ Tensor Model::run_net(const Tensor& x) {
         t.N = B; t.C = C; t.H = max_bin; t.W = T;
         t.sH = T; t.sC = (long long)max_bin * T; t.sN = t.sC * C;
         t.p = ws.allocf((size_t)B * C * max_bin * T);
-        if (taping()) t.g = gs.allocf((size_t)B * C * max_bin * T);
+        if (taping()) t.g = galloc((size_t)B * C * max_bin * T, false);          // written through the full view and the band halves
         t.slope = training ? 0.f : 1.f;     // eval: dec1 / the tail convs store final activations
         return t;
     };

@@ -142,6 +142,8 @@ void Model::bwd_bn_of(const Tensor& out, Conv& L) {
     a.acc_grads = 1;
     a.coef = ws.allocf((size_t)out.C * 3);
     a.part = ws.allocf((size_t)bn_bwd_chunks(a) * out.C * 2);
+    if (!dry && g_first(out.g))            // no consumer wrote a gradient into this tensor (does not happen in this net): it is zero
+        prof_memset_async(out.g, 0, (size_t)out.N * out.C * out.H * out.W * sizeof(float), stream);
     if (!dry) launch_bn_bwd(a, stream);
 }
 
@@ -231,7 +233,7 @@ void Model::bwd_conv(TapeRec& r) {
         } else if (r.batch_as_h) {
             ds = ConvDst{t.g, 0, t.sC, t.sN, 1};
         } else {
-            ds = ConvDst{t.g, t.sN, t.sC, t.sH, 1};
+            ds = ConvDst{t.g, t.sN, t.sC, t.sH, (!dry && g_first(t.g)) ? 0 : 1};      // the tensor's first backward writer stores
         }
         d.dst[i] = ds;
         cbase += t.C;
@@ -302,7 +304,7 @@ void Model::bwd_conv(TapeRec& r) {
     record_end();
     for (auto& p : posts) {
         const Tensor& t = p.sp->t;
-        if (p.kind == 1) launch_upsample_bwd(p.tmp, N, t.C, t.H, t.W, t.g, t.sN, t.sC, t.sH, stream);
+        if (p.kind == 1) launch_upsample_bwd(p.tmp, N, t.C, t.H, t.W, t.g, t.sN, t.sC, t.sH, g_first(t.g) ? 0 : 1, stream);
         else launch_sum_h(p.tmp, N, t.C, f.Hin, f.Win, t.g, stream);
     }
 }
@@ -350,7 +352,7 @@ void Model::backward() {
             break;
         case TK_AVGPOOL: {
             const Tensor& x5 = r.srcs[0].t;
-            if (!dry && x5.g) launch_avgpool_bwd(r.out.g, x5.g, r.N, x5.C, x5.H, x5.W, x5.sN, x5.sC, x5.sH, stream);
+            if (!dry && x5.g) launch_avgpool_bwd(r.out.g, x5.g, r.N, x5.C, x5.H, x5.W, x5.sN, x5.sC, x5.sH, g_first(x5.g) ? 0 : 1, stream);
             break;
         }
         case TK_SQUEEZE: {
@@ -361,7 +363,7 @@ void Model::backward() {
             float* part = ws.allocf((size_t)thin_wgrad_blocks(h) * h.C);
             if (!dry) {
                 launch_thin_wgrad(h, 1, r.out.g, part, grad_of(M.squeeze.w), 1, stream);
-                launch_thin_dgrad(h, 1, M.squeeze.w->dev, r.out.g, h.g, 1, stream);
+                launch_thin_dgrad(h, 1, M.squeeze.w->dev, r.out.g, h.g, g_first(h.g) ? 0 : 1, stream);
             }
             break;
         }
@@ -408,6 +410,7 @@ void Model::train_fwd_bwd_api(const float* X, const float* Y, bool on_dev, int B
     // ---- plan: dry run of forward + backward sizes both arenas ----------------------------------------
     auto run_all = [&](const float* xd, const float* yd, float* maskd, float* lossd) {
         tape.clear();
+        g_fresh.clear(); gs_zero.clear();
         Tensor xt;
         xt.p = const_cast<float*>(xd); xt.N = B; xt.C = 2; xt.H = Hm; xt.W = T;
         xt.sH = T; xt.sC = (long long)output_bin * T; xt.sN = 2 * xt.sC; xt.slope = 1.f;
@@ -422,7 +425,7 @@ void Model::train_fwd_bwd_api(const float* X, const float* Y, bool on_dev, int B
             launch_head_loss(f3, out_w->dev, xd, yd, output_bin, (float)(1.0 / (ntot * accumulation_steps)), dlogit, maskd,
                              lpart, lossd, (float)(1.0 / ntot), stream);
             launch_thin_wgrad(f3, 2, dlogit, wpart, grad_of(out_w), 1, stream);
-            launch_thin_dgrad(f3, 2, out_w->dev, dlogit, f3.g, 1, stream);
+            launch_thin_dgrad(f3, 2, out_w->dev, dlogit, f3.g, g_first(f3.g) ? 0 : 1, stream);
         }
         backward();
     };
@@ -433,6 +436,7 @@ void Model::train_fwd_bwd_api(const float* X, const float* Y, bool on_dev, int B
         try { run_all(reinterpret_cast<float*>(uintptr_t(256)), nullptr, nullptr, nullptr); }
         catch (...) { dry = false; ws = sws; gs = sgs; tape.clear(); throw; }
         dry = false;
+        gs_zero_plan = gs_zero;                      // which buffers of gs need a zero fill (the real pass allocates in the same order)
         const size_t need_ws = ws.peak + (3 * io_floats + 64) * sizeof(float) + 8192, need_gs = gs.peak + 4096;
         ws = sws; gs = sgs;
         ensure_ws(need_ws);
@@ -448,11 +452,11 @@ void Model::train_fwd_bwd_api(const float* X, const float* Y, bool on_dev, int B
         if (!lanes.empty()) {
             VR_HIP(hipEventRecord(lanes[0].fork, stream));            // (previous step's consumers of gs are done)
             VR_HIP(hipStreamWaitEvent(lanes[0].main, lanes[0].fork, 0));
-            prof_memset_async(gs.base, 0, need_gs, lanes[0].main);
+            clear_gs_zero_ranges(lanes[0].main);
             VR_HIP(hipEventRecord(lanes[0].join, lanes[0].main));
             gs_clear_pending = true;
         } else {
-            prof_memset_async(gs.base, 0, need_gs, stream);
+            clear_gs_zero_ranges(stream);
         }
     }
     prepare_dropout(B);
@@ -498,6 +502,7 @@ void Model::forward_train_api(const float* X, bool on_dev, int B, int T, float* 
     const int Hm = max_bin;
     auto fwd = [&](const float* xd) {
         tape.clear();
+        g_fresh.clear(); gs_zero.clear();
         Tensor xt;
         xt.p = const_cast<float*>(xd); xt.N = B; xt.C = 2; xt.H = Hm; xt.W = T;
         xt.sH = T; xt.sC = (long long)output_bin * T; xt.sN = 2 * xt.sC; xt.slope = 1.f;
@@ -518,6 +523,7 @@ void Model::forward_train_api(const float* X, bool on_dev, int B, int T, float* 
             backward();
         } catch (...) { dry = false; ws = sws; gs = sgs; tape.clear(); throw; }
         dry = false;
+        gs_zero_plan = gs_zero;
         const size_t need_ws = ws.peak + 8192, need_gs = gs.peak + 4096;
         ws = sws; gs = sgs;
         ensure_ws(need_ws);
@@ -530,7 +536,7 @@ void Model::forward_train_api(const float* X, bool on_dev, int B, int T, float* 
         }
         ws.reset(); gs.reset();
         if (gs_clear_pending) { VR_HIP(hipStreamWaitEvent(stream, lanes[0].join, 0)); gs_clear_pending = false; }
-        prof_memset_async(gs.base, 0, need_gs, stream);
+        clear_gs_zero_ranges(stream);
     }
     prepare_dropout(B);
     float* xd = ws.allocf(io_floats);
@@ -566,7 +572,7 @@ void Model::backward_api(const float* dmask, bool on_dev) {
         float* wpart = ws.allocf((size_t)thin_wgrad_blocks(f3) * 2 * f3.C);
         launch_head_bwd(tmp, graph_mask, B, Hm, T, output_bin, dlogit, stream);
         launch_thin_wgrad(f3, 2, dlogit, wpart, grad_of(out_w), 1, stream);
-        launch_thin_dgrad(f3, 2, out_w->dev, dlogit, f3.g, 1, stream);
+        launch_thin_dgrad(f3, 2, out_w->dev, dlogit, f3.g, g_first(f3.g) ? 0 : 1, stream);
         backward();
         VR_HIP(hipStreamSynchronize(stream));
     } else {
@@ -574,7 +580,7 @@ void Model::backward_api(const float* dmask, bool on_dev) {
         float* wpart = ws.allocf((size_t)thin_wgrad_blocks(f3) * 2 * f3.C);
         launch_head_bwd(dm, graph_mask, B, Hm, T, output_bin, dlogit, stream);
         launch_thin_wgrad(f3, 2, dlogit, wpart, grad_of(out_w), 1, stream);
-        launch_thin_dgrad(f3, 2, out_w->dev, dlogit, f3.g, 1, stream);
+        launch_thin_dgrad(f3, 2, out_w->dev, dlogit, f3.g, g_first(f3.g) ? 0 : 1, stream);
         backward();
         VR_HIP(hipStreamSynchronize(stream));
     }
