@@ -1,6 +1,7 @@
-"""Overlap picture of one train step from a rocprofv3 kernel trace taken WITH the concurrent executor (rocpd database):
+"""Overlap picture of one step from a rocprofv3 kernel trace taken WITH the concurrent executor (rocpd database):
 per-queue busy time, the union (some kernel running), the sum of kernel durations and the largest idle gaps.  The step is the
-span between the last two adam_kernel launches.   Usage: timeline.py run.db [steps back from the end]"""
+span between two launches of a marker kernel: adam_kernel (train step, default) or e.g. stft_tile_kernel (inference: the first
+kernel of a separate_wave call).   Usage: timeline.py run.db [steps back from the end] [marker] [end|start]"""
 import re
 import sqlite3
 import sys
@@ -9,10 +10,12 @@ db = sqlite3.connect(sys.argv[1])
 cols = [c[1] for c in db.execute('pragma table_info(kernels)')]
 qcol = 'queue_id' if 'queue_id' in cols else ('stream_id' if 'stream_id' in cols else None)
 rows = db.execute('select name, start, end, %s from kernels order by start' % (qcol or '0')).fetchall()
-adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r[0]]
+marker = sys.argv[3] if len(sys.argv) > 3 else 'adam_kernel'
+at_start = len(sys.argv) > 4 and sys.argv[4] == 'start'      # the marker OPENS a step (inference) instead of closing it (train)
+adam = [i for i, r in enumerate(rows) if marker in r[0]]
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 1          # 1: the last step (bench.py: the serialised, profiled one), 2: the one before
 if len(adam) >= back + 1:
-    rows = rows[adam[-back - 1] + 1:adam[-back] + 1]
+    rows = rows[adam[-back - 1]:adam[-back]] if at_start else rows[adam[-back - 1] + 1:adam[-back] + 1]
 t0, t1 = rows[0][1], max(r[2] for r in rows)
 print('kernels %d, span %.2f ms, sum of durations %.2f ms' % (len(rows), (t1 - t0) / 1e6, sum(r[2] - r[1] for r in rows) / 1e6))
 byq = {}

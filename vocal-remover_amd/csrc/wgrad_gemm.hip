@@ -25,7 +25,11 @@ struct WgGemmCfg {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <bool BF>
+// KS (round 4): layers with at most 32 couts and 32 input channels (the stage tail convs 32 -> 16 / 16 -> 8 at full resolution: 2.1 M
+// pixels per channel) have ONE real 32 x 32 output tile -- in the blocked form seven of the eight waves multiplied zero padding and the
+// launch was bound by MFMAs on zeros (346 us for 400 MB).  Here the eight waves split the 64 pixels of a chunk instead (wave w takes
+// k-step w) and their accumulators are added in a fixed order through LDS at the end: HBM-bound, as the shape is.
+template <bool BF, bool KS = false>
 __global__ __launch_bounds__(512, 2) void wgrad_gemm_kernel(const WgradArgs a, int chunks_per_img, long long img_pixels) {
     using Cfg = WgGemmCfg;
     constexpr int MT = Cfg::MT, CB = Cfg::CB, KC = Cfg::KC, RP = Cfg::RP, D = Cfg::D, NI = Cfg::NI;
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_gemm_kernel(const WgradArgs a, i
     };
 
     const int khalf = lane >> 5, l31 = lane & 31;
-    const int mi = wave & 1, nb = wave >> 1;                           // this wave: couts [32*mi, +32) x input channels [32*nb, +32)
+    const int mi = KS ? 0 : (wave & 1), nb = KS ? 0 : (wave >> 1);     // this wave: couts [32*mi, +32) x input channels [32*nb, +32)
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -107,6 +111,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_gemm_kernel(const WgradArgs a, i
         const float* st = smem + ((pt - t_begin) % D) * Cfg::STAGE;
 #pragma unroll
         for (int q = 0; q < KC / 8; ++q) {
+            if (KS && q != wave) continue;                               // (KC / 8 == 8 k-steps == 8 waves)
             const f32x4v av = *reinterpret_cast<const f32x4v*>(st + a_off + 32 * q);
             const f32x4v bv = *reinterpret_cast<const f32x4v*>(st + b_off + 32 * q);
             if constexpr (BF) {
@@ -126,6 +131,28 @@ __global__ __launch_bounds__(512, 2) void wgrad_gemm_kernel(const WgradArgs a, i
     // ---- partial slab part[p][ci][CoutPad] (KS*KS = 1) -------------------------------------------------------------------
     float* pp = a.part + (long long)p * a.part_stride;
     const int ci = c0 + 32 * nb + l31;
+    if constexpr (KS) {
+        // the eight waves hold partial sums of the SAME tile: through LDS, added in wave order
+        __builtin_amdgcn_s_barrier();                                   // (every wave is past its last stage read)
+        float* red = smem;                                              // [8 waves][16 regs][64 lanes]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (wave < 2) {                                                 // wave 0: registers 0..7, wave 1: registers 8..15
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int r = wave * 8 + rr;
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) s += red[(w * 16 + r) * 64 + lane];
+                const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (ci < a.in.Cin && co < a.CoutPad) pp[(long long)ci * a.CoutPad + co] = s;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int co = co0 + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * khalf;
@@ -174,6 +201,14 @@ void wgrad_gemm_plan(WgradArgs& a) {
 void wgrad_gemm_launch(const WgradArgs& a, hipStream_t st) {
     static std::atomic<unsigned long long> attr_done{0}, attr_done_bf{0};          // per device (bit = device index)
     const int grid = ((a.P + 7) / 8) * 8 * a.nchunks * a.nct;
+    if (a.bf16 != 1 && a.CoutPad <= 32 && a.in.Cin <= 32) {                       // one real 32 x 32 tile: split the pixels over the waves
+        static std::atomic<unsigned long long> attr_done_ks{0};
+        ensure_lds_attr(attr_done_ks, reinterpret_cast<const void*>(wgrad_gemm_kernel<false, true>), WgGemmCfg::LDS_BYTES);
+        VR_LAUNCH((wgrad_gemm_kernel<false, true>), dim3(grid), dim3(512), WgGemmCfg::LDS_BYTES, st, a, a.tiles_w,
+                  (long long)a.in.Hout * a.in.Wout);
+        VR_HIP(hipGetLastError());
+        return;
+    }
     if (a.bf16 == 1) {
         ensure_lds_attr(attr_done_bf, reinterpret_cast<const void*>(wgrad_gemm_kernel<true>), WgGemmCfg::LDS_BYTES);
         VR_LAUNCH(wgrad_gemm_kernel<true>, dim3(grid), dim3(512), WgGemmCfg::LDS_BYTES, st, a, a.tiles_w,
