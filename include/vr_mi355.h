@@ -58,9 +58,9 @@ int vr_get_param(vr_handle h, const char* key, void* host, int64_t capacity_byte
 /* nn.Module.train() / eval()                                          inference.py:52, train.py:69,109 */
 int vr_set_mode(vr_handle h, int training);
 /* Numerical options.  "train_winograd" (default 1): train-mode forward and data-gradient 3x3 stride-1
- * convolutions use the Winograd F(2x2,3x3) kernel (fp32; rounding differs from the direct kernel by
- * ~1e-6 relative per conv -- the same class of difference as cuDNN's algorithm choice in the
- * reference); 0 = direct kernels only.  Inference always uses Winograd where applicable.
+ * convolutions may use the transformed-weight kernels (mfma_mode 0: Winograd F(2x2,3x3), fp32, rounding differs from the direct
+ * kernel by ~1e-6 relative per conv -- the same class of difference as cuDNN's algorithm choice in the reference; mfma_mode 2, the
+ * default: the split-bf16 direct kernel conv_x3.hip); 0 = the fp32 direct kernels only.  Eval follows "mfma_mode" alone.
  * "adam_reset": zero the Adam moments and the step counter (what constructing a new
  * torch.optim.Adam does; train.py:215-218).  "serial_exec" (default 0): 1 = every kernel on the handle's one
  * stream, no lanes / side streams (tests: results must not depend on the concurrent executor).
@@ -75,7 +75,14 @@ int vr_set_mode(vr_handle h, int training);
  *       the 1x1 weight-gradient GEMM round their operands to bf16 (RNE, in registers); accumulation, every stored tensor, the
  *       master weights and Adam stay fp32.   -1 = back to the handle's default (2, or VR_MFMA_MODE).
  * "mfma_bf16": 1 = "mfma_mode" 1; 0 = back to the handle's default mode.
- * "params_dirty": the parameter arena was written from outside (vr_param_arena).                              */
+ * "params_dirty": the parameter arena was written from outside (vr_param_arena).
+ * "hip_graph" (default 0, or VR_HIP_GRAPH): 1 = vr_separate_wave with device-resident input and outputs (and without
+ *   --postprocess) captures its whole launch sequence -- STFT, every crop of both lanes and their streams, masked iSTFT x2 -- as a
+ *   hipGraph on the second call with the same (length, flags, batchsize, cropsize) and replays it afterwards: one hipGraphLaunch
+ *   instead of ~300 kernel launches.  Results are bit-equal either way (tests); measured 7-8 % slower than the eager enqueue on
+ *   ROCm 7.0, hence opt-in.
+ * "conv_x3p" (default 0, or VR_CONV_X3P): eval only -- 1 = the 3x3 stride-1 convolutions read activations stored as three bf16
+ *   planes (csrc/conv_x3p.hip); measured on a par with the default path, kept as an option.              */
 int vr_set_option(vr_handle h, const char* name, int value);
 
 /* CascadedNet.forward (mode 0) / predict_mask (mode 1) / predict (mode 2)   lib/nets.py:82-141
@@ -162,7 +169,8 @@ int vr_get_grad(vr_handle h, const char* key, float* host, int64_t capacity_byte
  * stg1_low, stg1_high, stg2_low, stg2_high, stg3_full, row pitch 8*c of each net.                   */
 int vr_set_dropout(vr_handle h, int mode, uint64_t seed, const float* masks, int B);
 /* The single flat fp32 gradient bucket (device pointer + element count) for the data-parallel
- * all-reduce (RCCL through torch.distributed): all-reduce it in place, then vr_adam_step.           */
+ * all-reduce: vr_allreduce_grads sums it in place with the library's own RCCL communicator (or a caller may reduce this view
+ * through torch.distributed -- Trainer(backend='torch' | 'staged')), then vr_adam_step.                                      */
 int vr_grad_arena(vr_handle h, float** device_ptr, int64_t* numel);
 
 /* One batch of train.validate_epoch (train.py:117-127), eval mode:

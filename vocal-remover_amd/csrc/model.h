@@ -138,6 +138,8 @@ public:
     // wave [2,L] -> y_wave, v_wave [2, hop*(T-1)]: whole inference.py pipeline, device resident
     void separate_wave_api(const float* wave, bool on_dev, long long L, int tta, int batchsize, int cropsize,
                            float* y_wave, float* v_wave, bool out_on_dev);
+    void separate_wave_body(const float* wave, bool on_dev, long long L, int tta, int batchsize, int cropsize,
+                            float* y_wave, float* v_wave, bool out_on_dev, bool staged_device_io);
 
     // ---- debug / test hooks ----
     void debug_conv(const float* x, int N, int Cin, int H, int W, const float* w_oihw, int Cout, int KS, int stride,
@@ -169,6 +171,26 @@ public:
     void reset_adam_state();
     void profile_end(double* conv_ms, double* conv_flops, double* conv_bytes, int* launches);
 
+    // ---- hipGraph replay of the device-resident inference pipeline (separate_wave_api) ---------------------------------------
+    // One song = ~300 launches over 2 lanes x 2 streams in ~10 ms: enqueued from one host thread the second lane starts late and a
+    // serialised step shows ~10 us between kernels.  With input and outputs resident in HBM the whole call (STFT -> crops ->
+    // CascadedNet -> stitch -> masked iSTFT x2, all lanes and streams, their fork / join events) can be captured once per
+    // (length, flags, batch, crop) and replayed with one hipGraphLaunch; the wave is copied into / the stems out of fixed staging
+    // buffers around it.  Anything that may move a buffer or change the kernel choice bumps graph_epoch and drops the graph.
+    // OPT-IN (vr_set_option "hip_graph" / VR_HIP_GRAPH=1): on ROCm 7.0 the replay measured 7-8 % SLOWER than the eager enqueue, and a
+    // capture with forks inside both lanes crashes hipStreamEndCapture (the second lane therefore runs unforked inside the graph).
+    struct SepGraph { long long L = -1; int tta = 0, batchsize = 0, cropsize = 0; unsigned long long epoch = 0; int seen = 0;
+                      hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
+    SepGraph sep_graph;
+    float *sep_stage_y = nullptr, *sep_stage_v = nullptr;   // where separate_wave_body left the stems (staging buffers inside `io`)
+    unsigned long long graph_epoch = 1;
+    bool capturing = false;                              // inside hipStreamBeginCapture: no host synchronisation, no allocation
+    int graph_opt = -1;                                  // vr_set_option("hip_graph"): -1 default (VR_HIP_GRAPH, else OFF), 0 off, 1 on
+    bool graphs_on() const;
+    std::vector<hipEvent_t> cap_events; size_t cap_events_used = 0;
+    hipEvent_t ev(hipEvent_t regular);                   // capture: a fresh event per fork / join
+    void drop_sep_graph();
+    void sync_stream() { if (!capturing) VR_HIP(hipStreamSynchronize(stream)); }
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;          // eval mode: the high-band chain runs here
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;

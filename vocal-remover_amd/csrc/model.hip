@@ -235,6 +235,8 @@ void Model::finalize_layout() {
 }
 
 Model::~Model() {
+    drop_sep_graph();
+    for (hipEvent_t e : cap_events) hipEventDestroy(e);
     if (g_launch_prof == launch_prof) g_launch_prof = nullptr;
     prof_destroy(launch_prof);
     int prev_dev = -1;
@@ -372,6 +374,8 @@ void Model::refresh_x3p() {
 
 void Model::set_option(const std::string& name, int value) {
     plan_peak = 0;                                           // kernel choice and scratch layout depend on the options: re-plan the next forward
+    ++graph_epoch;                                           // ... and a captured inference graph has them baked in
+    if (name == "hip_graph") { graph_opt = value < 0 ? -1 : (value != 0); return; }
     if (name == "train_winograd") train_wino = value != 0;
     else if (name == "serial_exec") serial = value != 0;     // every kernel on the handle's one stream (race detector of the tests)
     else if (name == "params_dirty") affine_dirty = true;    // the parameter arena was written from outside (vr_param_arena)
@@ -521,8 +525,34 @@ void Model::run_wino_batch(WinoBatch& b, std::vector<WinoWDesc>& descs, bool spl
 // =====================================================================================================
 // workspace
 // =====================================================================================================
+bool Model::graphs_on() const {
+    // default OFF: measured SLOWER than the eager 2 lanes x 2 streams enqueue (S30 song: 11.66 vs 10.84 ms, --tta 23.85 vs 22.05 ms)
+    static const bool env_on = [] { const char* e = getenv("VR_HIP_GRAPH"); return e && atoi(e) != 0; }();
+    return graph_opt < 0 ? env_on : graph_opt != 0;
+}
+
+// While capturing, every fork / join gets its own event: re-recording one event object several times inside a capture crashed
+// hipStreamEndCapture (ROCm 7.0: segmentation fault with the 2 lanes x 2 streams of one song; a single stream captures fine).
+hipEvent_t Model::ev(hipEvent_t regular) {
+    if (!capturing) return regular;
+    if (cap_events_used == cap_events.size()) {
+        hipEvent_t e = nullptr;
+        VR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        cap_events.push_back(e);
+    }
+    return cap_events[cap_events_used++];
+}
+
+void Model::drop_sep_graph() {
+    if (sep_graph.exec) hipGraphExecDestroy(sep_graph.exec);
+    if (sep_graph.graph) hipGraphDestroy(sep_graph.graph);
+    sep_graph = SepGraph{};
+}
+
 void Model::ensure_ws(size_t bytes) {
     if (bytes <= ws.cap) return;
+    VR_CHECK(!capturing, -3, "workspace growth during graph capture");
+    ++graph_epoch;
     VR_HIP(hipStreamSynchronize(stream));
     if (ws.base) VR_HIP(hipFree(ws.base));
     ws.base = nullptr; ws.cap = 0;
@@ -544,6 +574,8 @@ void Model::swap_lane(int i) {
 
 void Model::ensure_io(size_t bytes) {
     if (bytes <= io.cap) return;
+    VR_CHECK(!capturing, -3, "staging growth during graph capture");
+    ++graph_epoch;
     VR_HIP(hipStreamSynchronize(stream));
     if (io.base) VR_HIP(hipFree(io.base));
     io.base = nullptr; io.cap = 0;
@@ -1061,8 +1093,9 @@ Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, co
     const bool afk = aspp_fork && !serial && !training && !dry && !profiling && side_stream != nullptr && !band_fork_active;
     hipStream_t aspp_main = stream;
     if (afk) {
-        VR_HIP(hipEventRecord(ev_fork, aspp_main));
-        VR_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
+        hipEvent_t ef = ev(ev_fork);
+        VR_HIP(hipEventRecord(ef, aspp_main));
+        VR_HIP(hipStreamWaitEvent(side_stream, ef, 0));
     }
     for (int j = 0; j < 4; ++j) {
         Tensor v = cat4;
@@ -1074,8 +1107,9 @@ Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, co
     }
     if (afk) {
         stream = aspp_main;
-        VR_HIP(hipEventRecord(ev_join, side_stream));
-        VR_HIP(hipStreamWaitEvent(aspp_main, ev_join, 0));
+        hipEvent_t ej = ev(ev_join);
+        VR_HIP(hipEventRecord(ej, side_stream));
+        VR_HIP(hipStreamWaitEvent(aspp_main, ej, 0));
     }
     SrcSpec s1{f1};
     s1.bcastH = x5.H;          // bilinear from H=1 with align_corners=True is a broadcast along H
@@ -1097,18 +1131,21 @@ Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, co
     static const bool lstm_fork = !getenv("VR_NO_LSTM_FORK");
     const bool fk = lstm_fork && !serial && !training && !dry && !profiling && side_stream != nullptr && !band_fork_active;
     SrcSpec uh;
+    hipEvent_t lstm_join = nullptr;
     if (fk) {
         hipStream_t ms = stream;
-        VR_HIP(hipEventRecord(ev_fork, ms));
-        VR_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
+        hipEvent_t ef = ev(ev_fork);
+        VR_HIP(hipEventRecord(ef, ms));
+        VR_HIP(hipStreamWaitEvent(side_stream, ef, 0));
         stream = side_stream;
         try { uh = upsampled(h); } catch (...) { stream = ms; throw; }
-        VR_HIP(hipEventRecord(ev_join, side_stream));
+        lstm_join = ev(ev_join);
+        VR_HIP(hipEventRecord(lstm_join, side_stream));
         stream = ms;
     }
     Tensor l = run_lstm(B.lstm, h);
     tap(p + ".lstm", l);
-    if (fk) VR_HIP(hipStreamWaitEvent(stream, ev_join, 0));
+    if (fk) VR_HIP(hipStreamWaitEvent(stream, lstm_join, 0));
     else uh = upsampled(h);
     SrcSpec ul = upsampled(l);
     Tensor o = run_conv(B.dec[3], {uh, ul, SrcSpec{e[0]}}, N, out_view, nullptr, false);
@@ -1147,8 +1184,9 @@ Tensor Model::run_net(const Tensor& x) {
     const bool fork = band_fork && !serial && !dry && (!training || train_fork) && !profiling && side_stream != nullptr;
     hipStream_t main_stream = stream;
     if (fork) {
-        VR_HIP(hipEventRecord(ev_fork, main_stream));
-        VR_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
+        hipEvent_t ef = ev(ev_fork);
+        VR_HIP(hipEventRecord(ef, main_stream));
+        VR_HIP(hipStreamWaitEvent(side_stream, ef, 0));
         band_fork_active = true;                 // until the join: the side stream belongs to the high-band chain
     }
     Tensor l1r = run_basenet(nets_[0], {SrcSpec{xl}}, B, nullptr);
@@ -1165,9 +1203,10 @@ Tensor Model::run_net(const Tensor& x) {
     Tensor h2 = run_basenet(nets_[3], {SrcSpec{xh}, SrcSpec{h1}}, B, &v);
     for (size_t i = tape_hi0; i < tape.size(); ++i) tape[i].chain = 1;    // backward may run these beside the low chain
     if (fork) {
-        VR_HIP(hipEventRecord(ev_join, side_stream));
+        hipEvent_t ej = ev(ev_join);
+        VR_HIP(hipEventRecord(ej, side_stream));
         stream = main_stream;
-        VR_HIP(hipStreamWaitEvent(main_stream, ev_join, 0));
+        VR_HIP(hipStreamWaitEvent(main_stream, ej, 0));
         band_fork_active = false;
     }
     tap("l1", l1); tap("h1", h1);
@@ -1498,6 +1537,8 @@ void Model::separate_api(const float* spec, bool on_dev, int T, int tta, int bat
             // crops [i, i+nb) in K contiguous parts; part 0 on the handle's own streams, part j on lane j-1
             for (Lane& l : lanes) {
                 if (l.ws.cap >= ws.cap) continue;            // every lane plans for the same (bs, cropsize)
+                VR_CHECK(!capturing, -3, "lane workspace growth during graph capture");
+                ++graph_epoch;
                 VR_HIP(hipDeviceSynchronize());
                 if (l.ws.base) VR_HIP(hipFree(l.ws.base));
                 l.ws.base = nullptr; l.ws.cap = 0;
@@ -1506,16 +1547,22 @@ void Model::separate_api(const float* spec, bool on_dev, int T, int tta, int bat
             }
             const int per = (nb + K - 1) / K;
             for (int j = 1; j < K; ++j) {                    // `mag` is ready at this point of the main stream
-                VR_HIP(hipEventRecord(lanes[j - 1].start, stream));
-                VR_HIP(hipStreamWaitEvent(lanes[j - 1].main, lanes[j - 1].start, 0));
+                hipEvent_t es = ev(lanes[j - 1].start);
+                VR_HIP(hipEventRecord(es, stream));
+                VR_HIP(hipStreamWaitEvent(lanes[j - 1].main, es, 0));
             }
             run_crops(i, std::min(per, nb));
             for (int j = 1; j < K; ++j) {
                 const int first = j * per, count = std::min(per, nb - first);
                 if (count <= 0) break;
                 swap_lane(j - 1);
-                try { run_crops(i + first, count); } catch (...) { swap_lane(j - 1); throw; }
-                hipEvent_t done = lanes[j - 1].done;
+                // (capture: the second lane keeps its two band chains on one stream -- with forks inside BOTH lanes hipStreamEndCapture
+                // crashes on ROCm 7.0, whichever of the band / ASPP / LSTM forks it is; each lane alone, or lanes without inner forks, capture fine)
+                hipStream_t side_saved = side_stream;
+                if (capturing) side_stream = nullptr;
+                try { run_crops(i + first, count); } catch (...) { side_stream = side_saved; swap_lane(j - 1); throw; }
+                side_stream = side_saved;
+                hipEvent_t done = ev(lanes[j - 1].done);
                 VR_HIP(hipEventRecord(done, stream));
                 swap_lane(j - 1);
                 VR_HIP(hipStreamWaitEvent(stream, done, 0));
@@ -1544,7 +1591,7 @@ void Model::separate_api(const float* spec, bool on_dev, int T, int tta, int bat
         for (int which = 0; which < 2; ++which)
             launch_istft_masked(plan, reinterpret_cast<const float2*>(sd), hop, T, mask[0], Wm[0], tta ? mask[1] : nullptr, Wm[1],
                                 roi / 2, wgt, which, which ? v_wave_d : y_wave_d, stream);
-        VR_HIP(hipStreamSynchronize(stream));
+        sync_stream();
         return;
     }
     launch_apply_mask(reinterpret_cast<const float2*>(sd), bins, T, mask[0], Wm[0], tta ? mask[1] : nullptr, Wm[1], roi / 2,
@@ -1560,26 +1607,118 @@ void Model::separate_wave_api(const float* wave, bool on_dev, long long L, int t
                               float* y_wave, float* v_wave, bool out_on_dev) {
     DeviceGuard dev_guard(device);
     VR_CHECK(L >= hop, -2, "wave shorter than one hop");
+    const bool graphable = on_dev && out_on_dev && !(tta & 2) && graphs_on() && !profiling && !serial && !record_taps && !training &&
+                           istft_masked_available(plan, hop) && L / hop >= 1;
+    if (!graphable) {
+        separate_wave_body(wave, on_dev, L, tta, batchsize, cropsize, y_wave, v_wave, out_on_dev, false);
+        return;
+    }
+    fold_eval_affines();                                 // (may launch table refreshes and synchronise: outside the graph)
+    SepGraph& g = sep_graph;
+    const bool same = g.L == L && g.tta == tta && g.batchsize == batchsize && g.cropsize == cropsize && g.epoch == graph_epoch;
+    if (!same) {
+        drop_sep_graph();
+        g.L = L; g.tta = tta; g.batchsize = batchsize; g.cropsize = cropsize; g.epoch = graph_epoch; g.seen = 0;
+    }
+    const size_t in_bytes = (size_t)2 * L * sizeof(float);
+    const size_t out_bytes = (size_t)2 * hop * (size_t)(L / hop) * sizeof(float);
+    if (!g.exec && g.seen >= 1) {
+        // second call with this shape: everything is allocated, planned and attribute-set -- capture it
+        hipGraph_t graph = nullptr;
+        static const bool gdbg = getenv("VR_GRAPH_DEBUG") != nullptr;
+        if (gdbg) fprintf(stderr, "[graph] begin capture\n");
+        cap_events_used = 0;
+        VR_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        capturing = true;
+        // every other stream joins the capture as a DIRECT child of the origin stream first (and is joined back at the end): with
+        // lane 1's side stream entering only through lane 1's main stream -- a fork of a fork -- hipStreamEndCapture crashed (ROCm 7.0)
+        std::vector<hipStream_t> others;
+        if (side_stream) others.push_back(side_stream);
+        for (Lane& l : lanes) { if (l.main) others.push_back(l.main); if (l.side) others.push_back(l.side); }
+        {
+            hipEvent_t root = ev(nullptr);
+            VR_HIP(hipEventRecord(root, stream));
+            for (hipStream_t o : others) VR_HIP(hipStreamWaitEvent(o, root, 0));
+        }
+        static const bool gser = getenv("VR_GRAPH_SERIAL") != nullptr;
+        const bool serial_saved = serial;
+        if (gser) serial = true;
+        try {
+            separate_wave_body(nullptr, true, L, tta, batchsize, cropsize, nullptr, nullptr, true, true);
+            serial = serial_saved;
+            for (hipStream_t o : others) {
+                hipEvent_t j = ev(nullptr);
+                VR_HIP(hipEventRecord(j, o));
+                VR_HIP(hipStreamWaitEvent(stream, j, 0));
+            }
+        } catch (...) {
+            capturing = false;
+            serial = serial_saved;
+            hipStreamEndCapture(stream, &graph);
+            if (graph) hipGraphDestroy(graph);
+            throw;
+        }
+        capturing = false;
+        if (gdbg) fprintf(stderr, "[graph] body enqueued\n");
+        VR_HIP(hipStreamEndCapture(stream, &graph));
+        if (gdbg) fprintf(stderr, "[graph] capture ended\n");
+        hipGraphExec_t exec = nullptr;
+        const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (gdbg) fprintf(stderr, "[graph] instantiate rc %d\n", (int)e);
+        if (e != hipSuccess || g.epoch != graph_epoch) {          // (an epoch bump during capture cannot happen: growth throws)
+            if (exec) hipGraphExecDestroy(exec);
+            hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            g.seen = -1000000;                                     // do not try again for this shape
+        } else {
+            g.graph = graph; g.exec = exec;
+        }
+    }
+    if (g.exec) {
+        // the staging layout of separate_wave_body(staged_device_io): wave at the start of `io`, the stems behind the spectrogram buffers
+        float* win = reinterpret_cast<float*>(io.base);
+        VR_HIP(hipMemcpyAsync(win, wave, in_bytes, hipMemcpyDeviceToDevice, stream));
+        VR_HIP(hipGraphLaunch(g.exec, stream));
+        { static const bool gd = getenv("VR_GRAPH_DEBUG") != nullptr; if (gd) fprintf(stderr, "[graph] launched\n"); }
+        VR_HIP(hipMemcpyAsync(y_wave, sep_stage_y, out_bytes, hipMemcpyDeviceToDevice, stream));
+        VR_HIP(hipMemcpyAsync(v_wave, sep_stage_v, out_bytes, hipMemcpyDeviceToDevice, stream));
+        VR_HIP(hipStreamSynchronize(stream));
+        return;
+    }
+    separate_wave_body(wave, true, L, tta, batchsize, cropsize, y_wave, v_wave, true, false);
+    if (g.seen >= 0) g.seen += 1;
+}
+
+// staged_device_io (graph capture): the input wave is expected at a fixed staging buffer (start of `io`) and the stems are left in
+// fixed staging buffers (sep_stage_y / sep_stage_v) -- the caller copies around the graph launch; no host copies, no synchronisation.
+void Model::separate_wave_body(const float* wave, bool on_dev, long long L, int tta, int batchsize, int cropsize,
+                               float* y_wave, float* v_wave, bool out_on_dev, bool staged_device_io) {
     const int T = 1 + (int)(L / hop);
     const int bins = output_bin;
     const size_t spec_f = (size_t)2 * bins * T * 2;
     const size_t out_f = (size_t)2 * hop * (T - 1);
     const size_t frames_f = (size_t)2 * T * n_fft;
     const size_t scratch = separate_scratch_floats(bins, T, cropsize, offset, tta);
+    // (the staging buffers of the graph path are always part of the layout, so that eager warm-up calls and the captured call agree)
     ensure_io(((size_t)2 * L + 3 * spec_f + 2 * out_f + frames_f + scratch) * sizeof(float) + 65536);
     io.reset();
+    float* stage_in = io.allocf((size_t)2 * L);
     const float* wd = wave;
-    if (!on_dev) {
-        float* tmp = io.allocf((size_t)2 * L);
-        VR_HIP(hipMemcpyAsync(tmp, wave, (size_t)2 * L * sizeof(float), hipMemcpyHostToDevice, stream));
-        wd = tmp;
+    if (staged_device_io) {
+        wd = stage_in;
+    } else if (!on_dev) {
+        VR_HIP(hipMemcpyAsync(stage_in, wave, (size_t)2 * L * sizeof(float), hipMemcpyHostToDevice, stream));
+        wd = stage_in;
     }
     float* spec = io.allocf(spec_f);
     float* ys = io.allocf(spec_f);
     float* vs = io.allocf(spec_f);
     float* frames = io.allocf(frames_f);
-    float* yw = out_on_dev ? y_wave : io.allocf(out_f + 4);
-    float* vw = out_on_dev ? v_wave : io.allocf(out_f + 4);
+    float* stage_y = io.allocf(out_f + 4);
+    float* stage_v = io.allocf(out_f + 4);
+    sep_stage_y = stage_y; sep_stage_v = stage_v;
+    float* yw = (out_on_dev && !staged_device_io) ? y_wave : stage_y;
+    float* vw = (out_on_dev && !staged_device_io) ? v_wave : stage_v;
     launch_stft(plan, wd, L, hop, T, reinterpret_cast<float2*>(spec), stream);
     if (istft_masked_available(plan, hop) && out_f) {
         separate_api(spec, true, T, tta, batchsize, cropsize, ys, vs, true, /*io_reserved=*/true, yw, vw);
@@ -1592,7 +1731,7 @@ void Model::separate_wave_api(const float* wave, bool on_dev, long long L, int t
         VR_HIP(hipMemcpyAsync(y_wave, yw, out_f * sizeof(float), hipMemcpyDeviceToHost, stream));
         VR_HIP(hipMemcpyAsync(v_wave, vw, out_f * sizeof(float), hipMemcpyDeviceToHost, stream));
     }
-    VR_HIP(hipStreamSynchronize(stream));
+    sync_stream();
 }
 
 // =====================================================================================================
