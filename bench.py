@@ -59,6 +59,7 @@ PROFILE_ROUND = 'r04'              # profiles/<round>_{infer,tta,train}_pmc.json
 # bytes for it, and reported as 'other' (latency / launch bound: LSTM recurrence, finalize kernels, descriptor refreshes) when not.
 KERNEL_CLASSES = (
     ('conv_x3_kernel', 'conv_x3: 3x3 stride-1 forward + data gradient, fp32 products from six bf16 products', 'bf16'),
+    ('conv_x3b_kernel', 'conv_x3: 3x3 stride-1 forward + data gradient, fp32 products from six bf16 products', 'bf16'),
     ('conv_x3p_kernel', 'conv_x3p: 3x3 stride-1 over bf16-plane tensors (option conv_x3p), fp32 products from six bf16 products', 'bf16'),
     ('wgrad_wino_kernel', 'wgrad_wino: 3x3 stride-1 weight gradient, Winograd F(3x3,2x2), fp32 MFMA', 'fp32'),
     ('conv_wino_kernel', 'conv_wino: 3x3 stride-1, Winograd F(2x2,3x3), fp32 MFMA (mfma_mode 0)', 'fp32'),

@@ -61,7 +61,8 @@ void launch_wino_weights_batched(const WinoWDesc* d_descs, int n, long long max_
 size_t wino_weights6_bytes(int Cin, int CoutPad);                                           // U as three bf16 planes (mfma_mode 2)
 void launch_wino_weights6(const float* w, void* u6, int Cin, int CoutPad, hipStream_t st);
 // conv_x3.hip: direct 3x3 stride-1 conv, fp32 products from six bf16 products (mfma_mode 2)
-struct X3Tile { int MT, TH; };
+struct X3Tile { int MT, TH; int b = 0; };          // b: conv_x3b.hip's 8-wave tiling
+void x3b_launch_conv(const ConvArgs& a, const X3Tile& t, hipStream_t st);
 struct X3WDesc { const float* w; void* o; int Cin, KK, CoutPad; };                            // one layer of a batched weight split
 bool x3_pick(const ConvArgs& a, const ConvShape& s, X3Tile* t);
 void x3_fill_tiling(ConvArgs& a, const X3Tile& t);
