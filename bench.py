@@ -373,11 +373,14 @@ class NativeWorkloads(object):
         if mfma_mode is not None:
             self.net.set_option('mfma_mode', mfma_mode)
 
-    def trainer(self, wire):
+    def trainer(self, wire, exchange_at_world1=False):
         from vocal_remover_amd import train as vtrain
         rt = self.rt
-        tr = vtrain.Trainer(self.net, lr=1e-3, world_size=rt.world, rank=rt.rank, backend='rccl' if rt.world > 1 else 'none',
-                            wire=wire if rt.world > 1 else 'fp32')
+        # exchange_at_world1 (configs[4] slice): the gradient bucket goes through the library's RCCL all-reduce in the wire format
+        # even on one GPU, so that the step that is timed is the step the 8-GPU job runs (bf16 rounding of the bucket included)
+        rccl = rt.world > 1 or exchange_at_world1
+        tr = vtrain.Trainer(self.net, lr=1e-3, world_size=rt.world, rank=rt.rank, backend='rccl' if rccl else 'none',
+                            wire=wire if rccl else 'fp32')
         g = torch.Generator().manual_seed(rt.rank)
         B = self.args.train_batch
         X = torch.rand((B, 2, N_FFT // 2 + 1, CROP), generator=g)
@@ -425,7 +428,7 @@ class StubWorkloads(object):
     def set_mode(self, mfma_mode=None, bf16=None):
         pass
 
-    def trainer(self, wire):
+    def trainer(self, wire, exchange_at_world1=False):
         rt = self.rt
 
         def reduce():
@@ -492,12 +495,12 @@ def main():
                'frames_per_step_per_gpu': T, 'ms_per_step_per_rank': [t / args.steps * 1e3 for t in rt.per_rank]}
         return res, step
 
-    def run_train(bf16=False, mfma_mode=None):
+    def run_train(bf16=False, mfma_mode=None, configs4=False):
         wl.set_mode(bf16=bf16)
         if mfma_mode is not None:
             wl.set_mode(mfma_mode=mfma_mode)
-        wire = 'bf16' if (bf16 and world > 1) else args.wire
-        step, reduce, zero_grad = wl.trainer(wire)
+        wire = 'bf16' if (configs4 or (bf16 and world > 1)) else args.wire
+        step, reduce, zero_grad = wl.trainer(wire, exchange_at_world1=configs4)
         B = args.train_batch
         dt = rt.timed(step, args.steps, args.warmup)
         per_rank = [t / args.steps * 1e3 for t in rt.per_rank]
@@ -517,8 +520,9 @@ def main():
         res = {'frames_per_sec': world * B * CROP * args.steps / dt, 'ms_per_step': dt / args.steps * 1e3,
                'ms_per_step_per_rank': per_rank, 'allreduce_ms': allreduce_ms,
                'global_batch': world * B, 'frames_per_step_per_gpu': B * CROP,
-               'workload': 'configs[3]: train.py step, batch %d x [2,1025,256] per GPU, fwd + L1 + bwd%s + Adam; '
-                           'Dropout2d live (library RNG)' % (B, ' + RCCL all-reduce (%s bucket)' % wire if world > 1 else ''),
+               'workload': 'configs[%d]: train.py step, batch %d x [2,1025,256] per GPU, fwd + L1 + bwd%s + Adam; '
+                           'Dropout2d live (library RNG)' % (4 if configs4 else 3, B,
+                                                             ' + RCCL all-reduce (%s bucket)' % wire if (world > 1 or configs4) else ''),
                'dtype': 'bf16 MFMA operands (Winograd forward / data-gradient / weight-gradient convs, 1x1 weight-gradient GEMM), '
                         'fp32 accumulation, storage, master weights and Adam; remaining convs fp32' if bf16 else SPLIT_DTYPE,
                'parallelism': 'dp%d (one RCCL all-reduce of the flat 14.74 M-element gradient bucket per step)' % world}
@@ -565,6 +569,7 @@ def main():
         tta_roof = roofline(tta_step, pmc('tta'))
         train_res, train_step_fn = run_train()
         train_roof = roofline(train_step_fn, pmc('train'))
+        c4_res, _ = run_train(configs4=True)
         # the same workloads with v_mfma_f32_32x32x2_f32 everywhere (mfma_mode 0: Winograd F(2x2,3x3) on the fp32 matrix pipe for the
         # 3x3 stride-1 layers, materialised decoder upsample) -- the round-1/2 arithmetic, beside the default above
         wl.set_mode(mfma_mode=0)
@@ -585,6 +590,19 @@ def main():
                             'global_batch': train_res['global_batch'], 'workload': train_res['workload'],
                             'parallelism': train_res['parallelism'], 'dtype': SPLIT_DTYPE, 'roofline': train_roof,
                             'ms_per_step_per_rank': train_res['ms_per_step_per_rank'], 'allreduce_ms': train_res['allreduce_ms']}
+            out['train_bf16'] = {
+                'metric': 'spectrogram-frames/sec (train-step, configs[4] slice: data-parallel step with the bf16 gradient bucket, %d GPU%s)' % (world, 's' if world > 1 else ''),
+                'value': c4_res['frames_per_sec'], 'ms_per_step': c4_res['ms_per_step'], 'steps': args.steps, 'warmup': args.warmup,
+                'global_batch': c4_res['global_batch'], 'workload': c4_res['workload'], 'parallelism': c4_res['parallelism'],
+                'ms_per_step_per_rank': c4_res['ms_per_step_per_rank'], 'allreduce_ms': c4_res['allreduce_ms'],
+                'dtype': 'bf16 where it is exact or harmless: the 3x3 stride-1 convolutions multiply on the bf16 matrix pipe (three-way split operands, '
+                         'six bf16 products per fp32 product: fp32-exact, mfma_mode 2) and the gradient bucket crosses xGMI in bf16 (rounded once, '
+                         'summed by RCCL in bf16, widened back); activations, master weights, accumulation and Adam stay fp32',
+                'what_it_is_not': 'a bf16-STORAGE pipeline: bf16 operands without the split lose the gradient direction on this net (cosine 0.37 vs fp32 at '
+                                  'batch 16, tests/test_gpu_b16.py) and storing the three bf16 planes (6 B per element) measured no faster than fp32 storage '
+                                  '(conv_x3p.hip, DESIGN.md section 3)',
+                'parity': 'tests/test_gpu_b16.py::test_b16_configs4_slice_vs_fp32: loss 1e-4 relative, global gradient cosine >= 0.99, per-tensor median >= 0.98 against '
+                          'mfma_mode 0 with the fp32 bucket at batch 16'}
             out['fp32_mfma'] = {
                 'what': "vr_set_option('mfma_mode', 0): every convolution on v_mfma_f32_32x32x2_f32 / 16x16x4 (fp32 operands; Winograd "
                         'F(2x2,3x3) for the 3x3 stride-1 layers, decoder upsample materialised) -- the default (mode 2) instead forms the '

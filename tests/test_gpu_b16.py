@@ -314,3 +314,49 @@ def test_b16_train_step_vs_cpu_oracle(vr, full16):
                 assert float((state[k] - sd32[k]).abs().max()) < 1e-4 * scale, k
             elif k.endswith('num_batches_tracked'):
                 assert int(state[k]) == int(sd32[k]), k
+
+
+def test_b16_configs4_slice_vs_fp32(vr, full16):
+    """configs[4] as this library runs it (bench.py `train_bf16`): the data-parallel step with bf16 where it is exact or harmless -- the
+    3x3 stride-1 convolutions on the bf16 matrix pipe with split-exact products (mfma_mode 2) and the gradient bucket rounded to bf16,
+    all-reduced by RCCL in bf16 and widened back (here world 1: the same kernels and the same rounding, one rank) -- against the fp32
+    step (mfma_mode 0, fp32 bucket) at the benched batch.  Bars: loss 1e-4 relative, global gradient cosine
+    >= 0.99, per-tensor cosine median >= 0.98."""
+    from vocal_remover_amd import train as vtrain
+    model, sd, X, y, masks = full16
+
+    def step(mode, wire):
+        try:
+            model.load_state_dict(sd)
+            model.set_option('mfma_mode', mode)
+            trainer = vtrain.Trainer(model, lr=1e-3, world_size=1, rank=0, backend='rccl', wire=wire, dropout=True, broadcast=False)
+            model.set_dropout_masks(masks)
+            model.zero_grad()
+            loss = model.train_step(X, y, 1)
+            trainer.reduce()                                         # vr_allreduce_grads in the wire format
+            torch.cuda.synchronize()
+            return loss, model.grads()
+        finally:
+            model.set_dropout_masks(None)
+            model.set_option('mfma_mode', -1)
+            model.eval()
+
+    try:
+        loss_a, g_a = step(0, 'fp32')
+        loss_b, g_b = step(2, 'bf16')
+    except vr.native.VRError as e:
+        pytest.skip('RCCL not usable on this box: %s' % e)
+    dot = na = nb = 0.0
+    cos = []
+    for k in g_a:
+        if k.endswith('dense.0.bias') or float(g_a[k].norm()) == 0.0:
+            continue
+        a, b = g_a[k].double().flatten(), g_b[k].double().flatten()
+        dot += float(a @ b); na += float(a @ a); nb += float(b @ b)
+        if a.numel() >= 64:
+            cos.append(float(a @ b / (a.norm() * b.norm() + 1e-300)))
+    gcos, med = dot / (na * nb) ** 0.5, float(np.median(cos))
+    print('configs[4] slice vs fp32 at batch 16: loss %.8f vs %.8f; gradient global cosine %.6f, per-tensor median %.5f, min %.4f'
+          % (loss_b, loss_a, gcos, med, min(cos)))
+    assert abs(loss_b - loss_a) <= 1e-4 * abs(loss_a)
+    assert gcos >= 0.99 and med >= 0.98
