@@ -572,10 +572,10 @@ size_t wgrad_scratch_floats(const WgradArgs& a_in, const ConvShape& s) {
         if (n > need) need = n;
     }
     if (s.KS == 3 && s.stride == 1 && s.dil_h == 1 && s.dil_w == 1 && a_in.allow_wino) {
-        for (int alt = 0; alt < 3; ++alt) {
+        for (int alt = 0; alt < 4; ++alt) {
             WgradArgs b = a_in;
-            if (b.CoutPad % (alt == 0 ? 64 : 32)) continue;
-            wgrad_wino_plan(b, alt == 1 ? 64 : 32, alt == 0 ? 64 : 32);
+            if (b.CoutPad % ((alt == 0 || alt == 3) ? 64 : 32)) continue;
+            wgrad_wino_plan(b, (alt == 1 || alt == 3) ? 64 : 32, (alt == 0 || alt == 3) ? 64 : 32);
             const size_t n = (size_t)b.P * (size_t)b.part_stride;
             if (n > need) need = n;
         }

@@ -22,6 +22,7 @@
 //     partial slab [ci][tap][co]; wgrad_reduce_kernel (wgrad_mfma.hip) sums the P slabs deterministically.
 // fp32 throughout; the transforms only add and halve.
 #include <cstdlib>
+#include <type_traits>
 
 #include "conv_stage.h"
 #include "lds_dma.h"
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const WgradArgs a) {
     const float* Vb = Vs + (2 * wave) * CB * KP + l31 * KP + khalf;   // + fi*CB*KP + ni*32*KP + 2*s
     for (int pt = t_begin; pt < t_end; ++pt) {
         if (pt + 1 < t_end) issue_chunk(pt + 1);       // the raw buffers were last read by this wave's own transform
+        if ((a.in.dbg & 64) && pt + 2 < t_end) issue_chunk(pt + 2);   // (timing experiment only: twice the bytes in flight, results are garbage)
         if constexpr (BF) {
             // bf16 operands: two v_mfma_f32_32x32x8_bf16 cover the chunk's 16 tiles of a frequency
             const float* Ub = Us + (2 * wave) * MT * KP + l31 * KP + 4 * khalf;
@@ -319,6 +321,325 @@ __global__ __launch_bounds__(512) void wgrad_wino_kernel(const WgradArgs a) {
     }
 }
 
+// ======================================================================================================================
+// Round 4: the same kernel with a REGISTER loader (wgrad_wino_r_kernel).
+//
+// What bounded the LDS-DMA form (profiles/r04_wgrad_wino_loader.txt): a workgroup has ONE chunk (35-53 KB) in flight, landing in
+// the single raw buffer the 16 frequency planes leave room for; its DMA takes ~2.6 us under load and overlaps only the multiply
+// phase of the previous chunk, so every chunk pays max(DMA, multiply) + transform -- and 256 CUs with one chunk in flight each draw
+// 3.9 TB/s where two in flight draw 5.2.  Here every lane loads the 4 x 4 input patches / 2 x 2 gradient tiles it transforms
+// straight into registers (global_load_dwordx2 for the two middle columns of a patch row, one dword for the outer column of the
+// chunk's first / last tile; the inner outer columns still come from the neighbour lanes by DPP), TWO chunks ahead: the loads of
+// chunk k+2 are issued behind the transform of chunk k and stay in flight across both barriers and the multiply phase.  No raw LDS
+// buffers, no DMA wait in front of the transform; zero padding, channels beyond Cin and chunks beyond the block's range read a
+// 16-byte zero page instead of being predicated, so every chunk issues the same number of loads and the hand-placed s_waitcnt
+// vmcnt(N) are compile-time constants (hipcc does not count inline-asm loads).
+// ======================================================================================================================
+__device__ __attribute__((aligned(16))) const float kWwZeroPage[4] = {0.f, 0.f, 0.f, 0.f};
+
+typedef float ww_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ww_f32x2 ww_load2(const float* p) {
+    ww_f32x2 v;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ float ww_load1(const float* p) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+template <int CB, int MT>
+struct WwrCfg {
+    static constexpr int TH = 4, TW = 16, KT = 16, KP = KT + 1;
+    static constexpr int XI = CB / 32, ZI = MT / 32;                   // transform iterations per wave: 4 channels / 4 couts each
+    static constexpr int NL = XI * 8 + ZI * 2;                          // loads per lane and chunk (4 row pairs + 4 edge words per x iteration)
+    static constexpr int VS = 16 * CB * KP, US = 16 * MT * KP;
+    static constexpr int LDS_FLOATS = VS + US;
+    static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+    static constexpr int WM = MT / 32, WN = CB / 32, MP = 33;
+    static_assert(16 * 32 * MP <= LDS_FLOATS && LDS_BYTES <= 160 * 1024 && 2 * NL < 60, "LDS / vmcnt");
+};
+
+template <int CB, int MT>
+struct WwRegs {                                                        // what one lane holds of one chunk
+    ww_f32x2 xm[WwrCfg<CB, MT>::XI][4];                                // patch rows 0..3, columns 1, 2
+    float xe[WwrCfg<CB, MT>::XI][4];                                   // the outer column of the chunk's first / last tile (column 0 / 3)
+    ww_f32x2 zg[WwrCfg<CB, MT>::ZI][2];                                // gradient tile rows 0, 1
+};
+
+// (32 x 32 blocks leave LDS for two workgroups per CU: one's transform / barrier waits fill with the other's multiply phase)
+template <int CB, int MT>
+__global__ __launch_bounds__(512, ((CB == 32 && MT == 32) ? 2 : 1)) void wgrad_wino_r_kernel(const WgradArgs a) {
+    using Cfg = WwrCfg<CB, MT>;
+    constexpr int TH = Cfg::TH, TW = Cfg::TW, KP = Cfg::KP, WM = Cfg::WM, WN = Cfg::WN, MP = Cfg::MP, XI = Cfg::XI, ZI = Cfg::ZI, NL = Cfg::NL;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Vs = smem;                                  // [16][CB][KP]
+    float* Us = Vs + Cfg::VS;                          // [16][MT][KP]
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int rr = id >> 3;
+    const int inner = a.nchunks * a.nct;
+    const int p = (rr / inner) * 8 + xcd;
+    if (p >= a.P) return;
+    const int ib = rr % inner;
+    const int ct = ib % a.nct, cb = ib / a.nct;
+    const int co0 = ct * MT, c0 = cb * CB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // 0..7
+    const int tiles_per_img = a.tiles_h * a.tiles_w;
+    const int t_begin = (int)((long long)p * a.npt / a.P), t_end = (int)((long long)(p + 1) * a.npt / a.P);
+
+    // lane = (tile k of the chunk, one of 4 channels / couts)
+    const int tk = lane & 15, tsub = lane >> 4;
+    const int ti = tk >> 3, tj = tk & 7;
+    const float* const zero = kWwZeroPage;
+
+    // ---- per-lane bases: the channels / couts this lane transforms are fixed for the workgroup -------------------------------
+    const float* xbase[XI];                            // source plane of the lane's channel (sample 0), or null past Cin
+    long long xsN[XI];
+    int xsH[XI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int ci = c0 + (CB / 8) * wave + 4 * i + tsub;
+        const bool live = ci < a.in.Cin;
+        const int cj = live ? ci : 0;
+        const int si = (cj >= a.in.c1) + (cj >= a.in.c2);
+        const int cbase = si == 0 ? 0 : (si == 1 ? a.in.c1 : a.in.c2);
+        const float* sp = si == 0 ? a.in.src[0].p : (si == 1 ? a.in.src[1].p : a.in.src[2].p);
+        const long long sC = si == 0 ? a.in.src[0].sC : (si == 1 ? a.in.src[1].sC : a.in.src[2].sC);
+        xsN[i] = si == 0 ? a.in.src[0].sN : (si == 1 ? a.in.src[1].sN : a.in.src[2].sN);
+        xsH[i] = (int)(si == 0 ? a.in.src[0].sH : (si == 1 ? a.in.src[1].sH : a.in.src[2].sH));
+        xbase[i] = live ? sp + (long long)(cj - cbase) * sC : nullptr;
+    }
+    const float* zbase[ZI];
+#pragma unroll
+    for (int i = 0; i < ZI; ++i) {
+        const int cg = co0 + 4 * (wave + 8 * i) + tsub;
+        zbase[i] = cg < a.Cout ? a.dz + (long long)cg * a.zC : nullptr;
+    }
+
+    // ---- loads of one chunk into a register set (always NL load instructions) -------------------------------------------------
+    auto load_chunk = [&](int pt, WwRegs<CB, MT>& R) {
+        const bool real = pt < t_end && !(a.in.dbg & 8);             // (dbg 8, timing only: every load reads the zero page)
+        const int ptc = real ? pt : t_begin;
+        const int n = ptc / tiles_per_img;
+        const int trem = ptc - n * tiles_per_img;
+        const int h0 = (trem / a.tiles_w) * TH, w0 = (trem % a.tiles_w) * TW;
+        const int wm = w0 + 2 * tj;                                   // image column of patch column 1
+        const int we = tj == 0 ? w0 - 1 : w0 + TW;                    // the outer column this lane may have to fetch itself
+        const bool edge_lane = real && (tj == 0 || tj == 7) && we >= 0 && we < a.in.Win;
+        const bool mid_ok = real && wm + 1 < a.in.Win;                // (Win % 4 == 0, wm even: the pair is inside or outside together)
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const float* xb = xbase[i] ? xbase[i] + (long long)n * xsN[i] : nullptr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int hr = h0 - 1 + 2 * ti + r;
+                const bool row_ok = xb != nullptr && hr >= 0 && hr < a.in.Hin;
+                const float* rowp = xb + (long long)hr * xsH[i];
+                R.xm[i][r] = ww_load2((row_ok && mid_ok) ? rowp + wm : zero);
+                R.xe[i][r] = ww_load1((row_ok && edge_lane) ? rowp + we : zero);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < ZI; ++i) {
+            const float* zb = zbase[i] ? zbase[i] + (long long)n * a.zN : nullptr;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int h = h0 + 2 * ti + r;
+                const bool ok = real && zb != nullptr && h < a.in.Hout && wm + 1 < a.in.Wout;
+                R.zg[i][r] = ww_load2(ok ? zb + (long long)h * a.zH + wm : zero);
+            }
+        }
+    };
+    // the registers of set R have landed when at most NEWER younger loads are outstanding; the asm names every register so that no
+    // consumer can be scheduled above the wait
+    auto wait_chunk = [&](WwRegs<CB, MT>& R, auto newer) {
+        constexpr int NEWER = decltype(newer)::value;
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NEWER) : "memory");
+#pragma unroll
+        for (int i = 0; i < XI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(R.xm[i][r]), "+v"(R.xe[i][r]));
+#pragma unroll
+        for (int i = 0; i < ZI; ++i)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) asm volatile("" : "+v"(R.zg[i][r]));
+    };
+
+    // ---- transforms of what this lane loaded (wgrad_wino_kernel's arithmetic) ---------------------------------------------------
+    auto transform = [&](WwRegs<CB, MT>& R) {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {                                 // B^T x B of 4 input channels
+            const int cl = (CB / 8) * wave + 4 * i + tsub;
+            float* V = Vs + cl * KP + tk;                              // + f * CB * KP
+            float d[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float m1 = R.xm[i][r][0], m2 = R.xm[i][r][1];
+                d[r][1] = m1; d[r][2] = m2;
+                const float left = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m2), 0x111, 0xf, 0xf, false));    // row_shr:1
+                const float right = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m1), 0x101, 0xf, 0xf, false));   // row_shl:1
+                d[r][0] = tj == 0 ? R.xe[i][r] : left;
+                d[r][3] = tj == 7 ? R.xe[i][r] : right;
+            }
+            float t[4][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                t[0][c] = d[0][c] - d[2][c];
+                t[1][c] = d[1][c] + d[2][c];
+                t[2][c] = d[2][c] - d[1][c];
+                t[3][c] = d[1][c] - d[3][c];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                V[(r * 4 + 0) * CB * KP] = t[r][0] - t[r][2];
+                V[(r * 4 + 1) * CB * KP] = t[r][1] + t[r][2];
+                V[(r * 4 + 2) * CB * KP] = t[r][2] - t[r][1];
+                V[(r * 4 + 3) * CB * KP] = t[r][1] - t[r][3];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < ZI; ++i) {                                 // G dz G^T of 4 couts
+            const int col = 4 * (wave + 8 * i) + tsub;
+            float* U = Us + col * KP + tk;                             // + f * MT * KP
+            const float g00 = R.zg[i][0][0], g01 = R.zg[i][0][1], g10 = R.zg[i][1][0], g11 = R.zg[i][1][1];
+            float t[4][2];
+            t[0][0] = g00;                 t[0][1] = g01;
+            t[1][0] = 0.5f * (g00 + g10);  t[1][1] = 0.5f * (g01 + g11);
+            t[2][0] = 0.5f * (g00 - g10);  t[2][1] = 0.5f * (g01 - g11);
+            t[3][0] = g10;                 t[3][1] = g11;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                U[(r * 4 + 0) * MT * KP] = t[r][0];
+                U[(r * 4 + 1) * MT * KP] = 0.5f * (t[r][0] + t[r][1]);
+                U[(r * 4 + 2) * MT * KP] = 0.5f * (t[r][0] - t[r][1]);
+                U[(r * 4 + 3) * MT * KP] = t[r][1];
+            }
+        }
+    };
+
+    const int khalf = lane >> 5, l31 = lane & 31;
+    f32x16 acc[2][WM][WN];
+#pragma unroll
+    for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[fi][mi][ni][r] = 0.f;
+
+    const float* Ua = Us + (2 * wave) * MT * KP + l31 * KP + khalf;   // + fi*MT*KP + mi*32*KP + 2*s
+    const float* Vb = Vs + (2 * wave) * CB * KP + l31 * KP + khalf;   // + fi*CB*KP + ni*32*KP + 2*s
+    auto multiply = [&]() {
+        // 16 k-steps (2 frequencies x 8 tile pairs), operands of step s+1 read before the MFMAs of step s
+        float av[WM], bv[WN];
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) av[mi] = Ua[mi * 32 * KP];
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) bv[ni] = Vb[ni * 32 * KP];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            float avn[WM], bvn[WN];
+            if (s + 1 < 16) {
+                const int fi = (s + 1) >> 3, kk = (s + 1) & 7;
+#pragma unroll
+                for (int mi = 0; mi < WM; ++mi) avn[mi] = Ua[fi * MT * KP + mi * 32 * KP + 2 * kk];
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni) bvn[ni] = Vb[fi * CB * KP + ni * 32 * KP + 2 * kk];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni)
+                    acc[s >> 3][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[s >> 3][mi][ni], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < 16) {
+#pragma unroll
+                for (int mi = 0; mi < WM; ++mi) av[mi] = avn[mi];
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni) bv[ni] = bvn[ni];
+            }
+        }
+    };
+
+    // chunk pt: [wait its registers] transform -> U, V | loads of chunk pt+2 | barrier | multiply | barrier
+    WwRegs<CB, MT> R0, R1;
+    using NLc = std::integral_constant<int, NL>;
+    if (t_begin < t_end) {
+        load_chunk(t_begin, R0);
+        load_chunk(t_begin + 1, R1);
+    }
+    const int dbg = a.in.dbg;                           // perf experiments only (VR_WW_DBG): 1 no transform, 2 no MFMA, 8 loads hit the zero page only
+    for (int pt = t_begin; pt < t_end; pt += 2) {
+        wait_chunk(R0, NLc{});                          // chunk pt landed (chunk pt+1 may be in flight)
+        if (!(dbg & 1)) transform(R0);
+        load_chunk(pt + 2, R0);
+        lds_barrier();
+        if (!(dbg & 2)) multiply();
+        if (pt + 1 < t_end) {
+            lds_barrier();                              // every wave is done reading U, V of chunk pt
+            wait_chunk(R1, NLc{});
+            if (!(dbg & 1)) transform(R1);
+            load_chunk(pt + 3, R1);
+            lds_barrier();
+            if (!(dbg & 2)) multiply();
+        }
+        if (pt + 2 < t_end) lds_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the prefetches past the block's range: zero-page loads nobody else waits for)
+
+    // ---------------- epilogue: gather the 16 frequencies per (cout, cin) through LDS, A^T M A -> 9 taps ---------------
+    float* Mx = smem;                                                  // [16][32 couts][MP]
+    float* pp = a.part + (long long)p * a.part_stride;
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) {
+            lds_barrier();                                             // main loop / previous pass has been read
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * khalf;          // cout within the 32-block
+                    Mx[((2 * wave + fi) * 32 + row) * MP + l31] = acc[fi][mi][ni][r];
+                }
+            lds_barrier();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = tid + 512 * j;
+                const int col = q & 31, cil = q >> 5;                  // lanes along couts: contiguous in the slab
+                float m[16];
+#pragma unroll
+                for (int f = 0; f < 16; ++f) m[f] = Mx[(f * 32 + col) * MP + cil];
+                float s0[4], s1[4], s2[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    s0[c] = m[c] + m[4 + c] + m[8 + c];
+                    s1[c] = m[4 + c] - m[8 + c];
+                    s2[c] = m[4 + c] + m[8 + c] - m[12 + c];
+                }
+                float y[9];
+                y[0] = s0[0] + s0[1] + s0[2]; y[1] = s0[1] - s0[2]; y[2] = s0[1] + s0[2] - s0[3];
+                y[3] = s1[0] + s1[1] + s1[2]; y[4] = s1[1] - s1[2]; y[5] = s1[1] + s1[2] - s1[3];
+                y[6] = s2[0] + s2[1] + s2[2]; y[7] = s2[1] - s2[2]; y[8] = s2[1] + s2[2] - s2[3];
+                const int ci = c0 + ni * 32 + cil;
+                const int co = co0 + mi * 32 + col;
+                if (ci < a.in.Cin && co < a.CoutPad) {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) pp[((long long)ci * 9 + t) * a.CoutPad + co] = y[t];
+                }
+            }
+        }
+    }
+}
+
 // ---- host side -----------------------------------------------------------------------------------------------------
 struct WwPick { int CB, MT; };
 
@@ -345,6 +666,11 @@ bool wgrad_wino_pick(const WgradArgs& a, const ConvShape& s, int* CB_out, int* M
     const bool m64 = a.CoutPad % 64 == 0;
     *MT_out = m64 ? 64 : 32;
     *CB_out = (!m64 && a.in.Cin > 32) ? 64 : 32;
+    // register loader (round 4): no raw LDS buffers, so 64 x 64 blocks fit beside the 16 frequency planes -- half the dz re-reads,
+    // a third fewer transform iterations and half the barriers per multiply-add of the layers with >= 64 input channels
+    static const bool b64 = [] { const char* e = getenv("VR_WW_B64"); return !e || atoi(e) != 0; }();
+    static const bool regl = [] { const char* e = getenv("VR_WW_REG"); return !e || atoi(e) != 0; }();
+    if (b64 && regl && a.bf16 != 1 && m64 && a.in.Cin > 32) *CB_out = 64;
     return true;
 }
 
@@ -374,10 +700,29 @@ static void ww_launch(const WgradArgs& a, hipStream_t st) {
     VR_HIP(hipGetLastError());
 }
 
+template <int CB, int MT>
+static void wwr_launch(const WgradArgs& a, hipStream_t st) {
+    using Cfg = WwrCfg<CB, MT>;
+    auto kern = wgrad_wino_r_kernel<CB, MT>;
+    static std::atomic<unsigned long long> attr_done{0};
+    ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
+    const int grid = ((a.P + 7) / 8) * 8 * a.nchunks * a.nct;
+    VR_LAUNCH(kern, dim3(grid), dim3(512), Cfg::LDS_BYTES, st, a);
+    VR_HIP(hipGetLastError());
+}
+
 void wgrad_wino_launch(const WgradArgs& a_in, int CB, int MT, hipStream_t st) {
     WgradArgs a = a_in;
     static const int dbg = [] { const char* e = getenv("VR_WW_DBG"); return e ? atoi(e) : 0; }();   // ablations (perf only)
     a.in.dbg = dbg;
+    static const bool reg_loader = [] { const char* e = getenv("VR_WW_REG"); return !e || atoi(e) != 0; }();
+    if (a.bf16 != 1 && reg_loader) {
+        if (CB == 64 && MT == 64) wwr_launch<64, 64>(a, st);
+        else if (CB == 32 && MT == 64) wwr_launch<32, 64>(a, st);
+        else if (CB == 64 && MT == 32) wwr_launch<64, 32>(a, st);
+        else wwr_launch<32, 32>(a, st);
+        return;
+    }
     if (a.bf16 == 1) {
         if (CB == 32 && MT == 64) ww_launch<32, 64, true>(a, st);
         else if (CB == 64 && MT == 32) ww_launch<64, 32, true>(a, st);
