@@ -8,16 +8,24 @@ import sqlite3
 import sys
 
 FAMILY = 'conv family (conv_x3 + conv_wino + conv_dma + conv_thin + conv_ws + conv_mfma + wgrad)'
-KEYS = ('conv_x3_kernel', 'conv_mfma_kernel', 'conv_ws_kernel', 'conv_dma_kernel', 'conv_dma_s2d_kernel', 'conv_thin_kernel', 'conv_wino_kernel',
-        'wgrad_ws_kernel', 'wgrad_mfma_kernel', 'wgrad_wino_kernel', 'wgrad_gemm_kernel')
+KEYS = ('conv_x3_kernel', 'conv_x3b_kernel', 'conv_x3p_kernel', 'conv_mfma_kernel', 'conv_ws_kernel', 'conv_dma_kernel', 'conv_dma_s2d_kernel',
+        'conv_thin_kernel', 'conv_wino_kernel', 'wgrad_ws_kernel', 'wgrad_mfma_kernel', 'wgrad_wino_kernel', 'wgrad_wino_r_kernel', 'wgrad_gemm_kernel')
+
+
+MEMBERS = {}          # counter -> {kernel name inside the conv family: (launches, value)}
 
 
 def load(path, counter):
     db = sqlite3.connect(path)
     out = {}
+    mem = MEMBERS.setdefault(counter, {})
     for name, val in db.execute("select name, counter_value from pmc_events where counter_name=? order by start", (counter,)):
         name = re.sub(r'^void ', '', name)
         conv = any(k in name for k in KEYS)
+        if conv:
+            short = re.sub(r'\(.*$', '', name)[:70]
+            n, s = mem.get(short, (0, 0.0))
+            mem[short] = (n + 1, s + val)
         name = FAMILY if conv else re.sub(r'\(.*$', '', name)[:60]
         n, s = out.get(name, (0, 0.0))
         out[name] = (n + 1, s + val)
@@ -30,6 +38,11 @@ print('| kernel | launches | FETCH_SIZE MB (raw) | WRITE_SIZE MB (raw) |')
 print('|---|---|---|---|')
 for k in sorted(f, key=lambda k: -f[k][1]):
     print('| %s | %d | %.1f | %.1f |' % (k, f[k][0], f[k][1] / 1024, w.get(k, (0, 0))[1] / 1024))
+print()
+print('| member of the conv family | launches | FETCH_SIZE MB (raw; x2 = bytes) | WRITE_SIZE MB (raw) |')
+print('|---|---|---|---|')
+for k in sorted(MEMBERS['FETCH_SIZE'], key=lambda k: -MEMBERS['FETCH_SIZE'][k][1]):
+    print('| %s | %d | %.1f | %.1f |' % (k, MEMBERS['FETCH_SIZE'][k][0], MEMBERS['FETCH_SIZE'][k][1] / 1024, MEMBERS.get('WRITE_SIZE', {}).get(k, (0, 0))[1] / 1024))
 if len(sys.argv) > 4:
     mode = sys.argv[5] if len(sys.argv) > 5 else 'infer'
     n, fk = f[FAMILY]
