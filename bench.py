@@ -61,7 +61,7 @@ KERNEL_CLASSES = (
     ('conv_x3_kernel', 'conv_x3: 3x3 stride-1 forward + data gradient, fp32 products from six bf16 products', 'bf16'),
     ('conv_x3b_kernel', 'conv_x3: 3x3 stride-1 forward + data gradient, fp32 products from six bf16 products', 'bf16'),
     ('conv_x3p_kernel', 'conv_x3p: 3x3 stride-1 over bf16-plane tensors (option conv_x3p), fp32 products from six bf16 products', 'bf16'),
-    ('wgrad_wino_kernel', 'wgrad_wino: 3x3 stride-1 weight gradient, Winograd F(3x3,2x2), fp32 MFMA', 'fp32'),
+    ('wgrad_wino_', 'wgrad_wino: 3x3 stride-1 weight gradient, Winograd F(3x3,2x2), fp32 MFMA', 'fp32'),
     ('conv_wino_kernel', 'conv_wino: 3x3 stride-1, Winograd F(2x2,3x3), fp32 MFMA (mfma_mode 0)', 'fp32'),
     ('conv_dma_kernel<1,', 'conv 1x1 (ASPP, tails, LSTM projection / dense), fp32 MFMA', 'fp32'),
     ('wgrad_gemm_kernel', 'conv 1x1 weight gradient, fp32 MFMA GEMM', 'fp32'),
@@ -475,6 +475,11 @@ def main():
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         self_launch(args)
+    # stdout carries ONE JSON line and nothing else: libraries write there too (RCCL prints a version banner at its first communicator,
+    # from C stdio), so file descriptor 1 points at stderr for the whole run and the line goes to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rt = Runtime(args)
     wl = (StubWorkloads if rt.stub else NativeWorkloads)(rt, args)
     world, rank, T = rt.world, rt.rank, wl.T
@@ -617,7 +622,8 @@ def main():
             out['cpu_baseline'] = wl.cpu_baseline('infer' if primary_mode in ('infer', 'tta') else 'train')
             if args.mode == 'all':
                 out['train']['cpu_baseline'] = wl.cpu_baseline('train')
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     rt.finish()
 
 

@@ -29,7 +29,7 @@ for m in train infer tta; do
   python tools/rocpd_summary.py $(ls $O/kt_$m/*.db | head -1) $O/${m}_kernel_trace.md > /dev/null
   timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_f_$m -o r -- python bench.py --mode $m --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc_f_$m.log 2>&1
   timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_w_$m -o r -- python bench.py --mode $m --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc_w_$m.log 2>&1
-  python tools/pmc_summary.py $(ls $O/pmc_f_$m/*.db | head -1) $(ls $O/pmc_w_$m/*.db | head -1) 2 $O/${m}_pmc.json $m > $O/${m}_pmc.md
+  python tools/pmc_summary.py $(ls $O/pmc_f_$m/*.db | head -1) $(ls $O/pmc_w_$m/*.db | head -1) 4 $O/${m}_pmc.json $m > $O/${m}_pmc.md
 done
 C="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"
 hipcc --offload-arch=gfx950 -O3 tools/mfma_peak.hip -o /tmp/mfma_peak 2>/dev/null
