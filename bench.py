@@ -59,6 +59,7 @@ PROFILE_ROUND = 'r04'              # profiles/<round>_{infer,tta,train}_pmc.json
 # bytes for it, and reported as 'other' (latency / launch bound: LSTM recurrence, finalize kernels, descriptor refreshes) when not.
 KERNEL_CLASSES = (
     ('conv_x3_kernel', 'conv_x3: 3x3 stride-1 forward + data gradient, fp32 products from six bf16 products', 'bf16'),
+    ('conv_x3h_kernel', 'conv_x3h: 3x3 stride-1 forward + data gradient, fp32-grade products from three fp16 products (mfma_mode 3)', 'f16x3'),
     ('conv_x3b_kernel', 'conv_x3: 3x3 stride-1 forward + data gradient, fp32 products from six bf16 products', 'bf16'),
     ('conv_x3p_kernel', 'conv_x3p: 3x3 stride-1 over bf16-plane tensors (option conv_x3p), fp32 products from six bf16 products', 'bf16'),
     ('wgrad_wino_', 'wgrad_wino: 3x3 stride-1 weight gradient, Winograd F(3x3,2x2), fp32 MFMA', 'fp32'),
@@ -220,14 +221,16 @@ def roofline_from_rows(rows, pmc_name, conv_totals):
     out = []
     for c in classes.values():
         ms, pipe = c['ms_per_step'], c.pop('pipe')
-        mult = 6.0 if pipe == 'bf16' else 1.0                     # executed products per fp32 product on the bf16 pipe
-        pk = {'bf16': BF16_MFMA_PEAK_TFLOPS, 'fp32': FP32_MFMA_PEAK_TFLOPS}.get(pipe)
+        # executed products per fp32 product: six on the bf16 pipe (conv_x3); conv_x3h issues 14 16-deep instructions per 9 taps x 8 channels
+        mult = {'bf16': 6.0, 'f16x3': 14 * 16 / 72.0}.get(pipe, 1.0)
+        pk = {'bf16': BF16_MFMA_PEAK_TFLOPS, 'f16x3': BF16_MFMA_PEAK_TFLOPS, 'fp32': FP32_MFMA_PEAK_TFLOPS}.get(pipe)
         t_flop = (mult * c['flops'] / (pk * 1e12) * 1e3) if pk else 0.0          # ms at the matrix-pipe peak
         t_byte = c['bytes'] / (HBM_PEAK_TBS * 1e12) * 1e3                         # ms at the HBM peak
         if pipe == 'none' or ms <= 0 or (t_flop == 0 and t_byte == 0):
             c.update({'bound': None, 'peak': None, 'achieved': None, 'unit': None, 'frac': None})
         elif t_flop >= t_byte:
             c.update({'bound': 'mfma', 'pipe': 'bf16 matrix pipe (v_mfma_f32_32x32x16_bf16), 6 executed products per fp32 product' if pipe == 'bf16'
+                      else 'fp16 matrix pipe (v_mfma_f32_32x32x16_f16, same dense peak as bf16), 3.11 executed products per fp32 product' if pipe == 'f16x3'
                       else 'fp32 matrix pipe (v_mfma_f32_32x32x2_f32 / 16x16x4)', 'peak': pk, 'unit': 'TFLOP/s',
                       'achieved': mult * c['flops'] / (ms * 1e-3) / 1e12, 'frac': t_flop / ms})
         else:

@@ -103,7 +103,7 @@ B16_CONVS = [
 ]
 
 
-@pytest.mark.parametrize('mode', [0, 2, 1], ids=['fp32_mfma', 'split_bf16', 'bf16_operands'])
+@pytest.mark.parametrize('mode', [0, 2, 3, 1], ids=['fp32_mfma', 'split_bf16', 'split_fp16', 'bf16_operands'])
 @pytest.mark.parametrize('case', B16_CONVS, ids=[str(c) for c in B16_CONVS])
 def test_b16_conv_dispatch_variants_vs_autograd(vr, full16, case, mode):
     """fp32 modes: 2e-4 of the tensor's scale.  bf16-operand mode (configs[4] arithmetic, kernels that have it): 2e-2 -- operands
@@ -228,7 +228,7 @@ def test_split_bf16_mode_is_fp32_exact_on_special_values(vr, full16, kind, shape
     nat = vr.native
     errs = {'torch cpu fp32': float(np.abs(cpu32.astype(np.float64) - want).max()) / scale}
     # fp32-MFMA direct kernel (mode 0, plain weights), fp32-MFMA Winograd (mode 0, transformed weights), split-bf16 direct (mode 2)
-    for key, mode, flags in (('fp32 MFMA direct', 0, 0), ('fp32 MFMA Winograd', 0, 2), ('split-bf16', 2, 2)):
+    for key, mode, flags in (('fp32 MFMA direct', 0, 0), ('fp32 MFMA Winograd', 0, 2), ('split-bf16', 2, 2), ('split-fp16', 3, 2)):
         got = np.empty(want.shape, np.float32)
         try:
             model.set_option('mfma_mode', mode)
@@ -241,6 +241,8 @@ def test_split_bf16_mode_is_fp32_exact_on_special_values(vr, full16, kind, shape
     print('%s %s: max error / scale  ' % (kind, shape) + '  '.join('%s %.3e' % kv for kv in errs.items()))
     # as exact as an fp32 DIRECT convolution (the Winograd form sums 2.25x fewer products and sits below all of them)
     assert errs['split-bf16'] <= 1.5 * max(errs['fp32 MFMA direct'], errs['torch cpu fp32']) + 1e-7
+    # mfma_mode 3 (conv_x3h.hip): operands scaled by exact powers of two per tile and chunk, two fp16 planes, three products
+    assert errs['split-fp16'] <= 2.5 * max(errs['fp32 MFMA direct'], errs['torch cpu fp32']) + 2e-7
 
 
 def test_b16_train_step_vs_cpu_oracle(vr, full16):

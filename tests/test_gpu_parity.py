@@ -191,7 +191,7 @@ def test_conv_x3_fused_upsample_vs_torch(vr, small, case):
     bn = bias.numpy() if bias is not None else None
     got = {}
     try:
-        for mode in (2, 0):
+        for mode in (2, 3, 0):
             model.set_option('mfma_mode', mode)
             out = np.empty(tuple(want.shape), np.float32)
             nat.check(nat.lib().vr_debug_conv2d(
@@ -203,9 +203,10 @@ def test_conv_x3_fused_upsample_vs_torch(vr, small, case):
         model.set_option('mfma_mode', -1)
     scale = float(want.abs().max())
     e2, e0 = float(np.abs(got[2] - want.numpy()).max()) / scale, float(np.abs(got[0] - want.numpy()).max()) / scale
-    print('fused upsample: split-bf16 direct %.2e, fp32 fused loader %.2e of the output scale' % (e2, e0))
-    assert e2 < 1e-4 and e0 < 1e-4
-    assert not np.array_equal(got[0], got[2])
+    e3 = float(np.abs(got[3] - want.numpy()).max()) / scale
+    print('fused upsample: split-bf16 direct %.2e, split-fp16 direct %.2e, fp32 fused loader %.2e of the output scale' % (e2, e3, e0))
+    assert e2 < 1e-4 and e0 < 1e-4 and e3 < 1e-4
+    assert not np.array_equal(got[0], got[2]) and not np.array_equal(got[3], got[2])
 
 
 SPLIT_CASES = [(3, 64, 128, 256, 64), (3, 61, 128, 256, 64), (3, 128, 64, 256, 128)]      # big enough for the 64-cout Winograd variant
@@ -230,7 +231,7 @@ def test_conv_winograd_split_bf16_mode_is_fp32_exact(vr, small, case):
     scale = float(np.abs(want).max())
     got = {}
     try:
-        for key, mode, flags in (('wino0', 0, 2), ('direct0', 0, 0), ('split', 2, 2)):
+        for key, mode, flags in (('wino0', 0, 2), ('direct0', 0, 0), ('split', 2, 2), ('half', 3, 2)):
             model.set_option('mfma_mode', mode)
             out = np.empty(want.shape, np.float32)
             nat.check(nat.lib().vr_debug_conv2d(model._handle.h, nat.np_ptr(x.numpy()), N, Cin, H, W, nat.np_ptr(w.numpy()), Cout, 3, 1, 1, 1,
@@ -249,6 +250,13 @@ def test_conv_winograd_split_bf16_mode_is_fp32_exact(vr, small, case):
     assert e_split[0] <= 1.5 * max(e_direct[0], e_cpu[0]) + 1e-7
     assert e_split[1] <= 1.5 * max(e_direct[1], e_cpu[1]) + 1e-7
     assert e_split[0] < 5e-6
+    # mfma_mode 3 (conv_x3h.hip: two fp16 planes per operand, three products): 22 significand bits per operand and one omitted
+    # 2^-22 term -- measured 1.3-2x an fp32 direct convolution's rounding error; bar 2.5x + 2e-7, and under 5e-6 absolute
+    e_half = err(got['half'])
+    print('split-fp16 (three products): %.2e / %.2e' % e_half)
+    assert not np.array_equal(got['half'], got['split']) and not np.array_equal(got['half'], got['direct0']), 'mode 3 fell back'
+    assert e_half[0] <= 2.5 * max(e_direct[0], e_cpu[0]) + 2e-7 and e_half[1] <= 2.5 * max(e_direct[1], e_cpu[1]) + 2e-7
+    assert e_half[0] < 5e-6
 
 
 def test_forward_taps_small_net(vr, small):
@@ -360,8 +368,9 @@ def test_predict_mask_full_net(full):
     assert float(want.std()) > 0.02
 
 
-def test_predict_mask_full_net_split_bf16_mode(full):
-    """The same configuration with mfma_mode 2: the SAME bars against the oracle, and agreement with mode 0 at rounding level."""
+@pytest.mark.parametrize('split_mode', [2, 3], ids=['six_bf16_products', 'three_fp16_products'])
+def test_predict_mask_full_net_split_bf16_mode(full, split_mode):
+    """The same configuration with mfma_mode 2 / 3: the SAME bars against the oracle, and agreement with mode 0 at rounding level."""
     model, sd = full
     x = torch.rand(2, 2, 1025, 256, generator=torch.Generator().manual_seed(2))
     with torch.no_grad():
@@ -369,7 +378,7 @@ def test_predict_mask_full_net_split_bf16_mode(full):
     model.set_option('mfma_mode', 0)
     ref = model.predict_mask(x.to('cuda:0')).cpu()
     try:
-        model.set_option('mfma_mode', 2)
+        model.set_option('mfma_mode', split_mode)
         got = model.predict_mask(x.to('cuda:0')).cpu()
     finally:
         model.set_option('mfma_mode', -1)

@@ -126,7 +126,7 @@ Model::Model(int device_, int n_fft_, int hop_, int nout_, int nout_lstm_)
     output_bin = n_fft / 2 + 1;
     VR_CHECK((max_bin / 2) % 16 == 0, -2, "n_fft/4 must be a multiple of 16 (four stride-2 encoders)");
     DeviceGuard dev_guard(device);
-    if (const char* e = getenv("VR_MFMA_MODE")) { mfma_mode = atoi(e); VR_CHECK(mfma_mode >= 0 && mfma_mode <= 2, -2, "VR_MFMA_MODE: 0, 1 or 2"); }
+    if (const char* e = getenv("VR_MFMA_MODE")) { mfma_mode = atoi(e); VR_CHECK(mfma_mode >= 0 && mfma_mode <= 3, -2, "VR_MFMA_MODE: 0, 1, 2 or 3"); }
     default_mfma_mode = mfma_mode;
     VR_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     if (!getenv("VR_NO_SIDE_STREAM")) {
@@ -381,7 +381,7 @@ void Model::set_option(const std::string& name, int value) {
     else if (name == "params_dirty") affine_dirty = true;    // the parameter arena was written from outside (vr_param_arena)
     else if (name == "mfma_bf16") { mfma_mode = value != 0 ? 1 : default_mfma_mode; affine_dirty = true; }   // bf16 operands on the matrix pipe (0: back to the handle's default mode)
     else if (name == "mfma_mode") {                          // 0 fp32 MFMA, 1 bf16 operands, 2 fp32 via 6 bf16 products (model.h); -1 = the default
-        if (value < -1 || value > 2) throw Error(-2, "mfma_mode: 0, 1, 2 or -1 (default)");
+        if (value < -1 || value > 3) throw Error(-2, "mfma_mode: 0, 1, 2, 3 or -1 (default)");
         mfma_mode = value < 0 ? default_mfma_mode : value; affine_dirty = true;   // (the next eval forward refreshes the derived weight copies)
     }
     else if (name == "conv_x3p") { x3p_opt = value < 0 ? -1 : (value != 0); affine_dirty = true; }   // eval: 3x3 stride-1 convs over bf16-plane tensors (conv_x3p.hip)
@@ -406,8 +406,8 @@ void Model::refresh_wino(bool with_dgrad) {
     }
     auto cin_pad = [](const Conv* L) { return (L->Cin + 31) / 32 * 32; };
     static const bool x3_on = !(getenv("VR_CONV_X3") && atoi(getenv("VR_CONV_X3")) == 0);
-    if (mfma_mode == 2 && x3_on) {
-        // split-bf16 copies of the DIRECT weights (conv_x3.hip takes every 3x3 stride-1 launch wide enough for its tiles)
+    if (x3_mode() && x3_on) {
+        // split-bf16 (mode 2) / split-fp16 (mode 3) copies of the DIRECT weights (conv_x3.hip takes every 3x3 stride-1 launch wide enough for its tiles)
         if (!x3_arena) {
             size_t total = 0;
             for (Conv* L : wino_list) total += x3_weights_bytes(L->Cin, 9, L->CoutPad);
@@ -498,7 +498,13 @@ void Model::run_x3_batch(X3Batch& b, std::vector<X3WDesc>& descs) {
         b.max_elems = 0;
         for (const X3WDesc& e : descs) b.max_elems = std::max(b.max_elems, (long long)((e.Cin + 7) / 8 * 8) * e.KK * e.CoutPad);
     }
-    launch_x3_weights_batched(b.dev, (int)descs.size(), b.max_elems, stream);
+    if (mfma_mode == 3) {
+        int mc = 0;
+        for (const X3WDesc& e : descs) mc = std::max(mc, e.CoutPad);
+        launch_x3h_weights_batched(b.dev, (int)descs.size(), b.max_elems, mc, stream);
+    } else {
+        launch_x3_weights_batched(b.dev, (int)descs.size(), b.max_elems, stream);
+    }
 }
 
 // One launch for a whole descriptor table; the device copy is re-uploaded only when the table changed.
@@ -856,7 +862,7 @@ Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs_in, int N, cons
         for (const SrcSpec& sp : srcs) any_up = any_up || sp.up;
         if (any_up) {
             ConvArgs probe = a;
-            probe.x3w = (mfma_mode == 2) ? L.x3w : nullptr;
+            probe.x3w = x3_mode() ? L.x3w : nullptr;
             probe.bf16 = mfma_mode;
             X3Tile xt;
             if (!x3_pick(probe, ConvShape{L.KS, L.stride, L.dh, L.dw}, &xt)) {
@@ -882,7 +888,7 @@ Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs_in, int N, cons
     if (fuse_epi) { a.epi = L.bn->affine; a.epi_slope = L.slope; }
     a.wino = (training && !train_wino) ? nullptr : L.wino;   // (null until the first refresh_wino())
     a.wino6 = (a.wino && mfma_mode == 2) ? L.wino6 : nullptr;
-    a.x3w = (mfma_mode == 2 && !(training && !train_wino)) ? L.x3w : nullptr;
+    a.x3w = (x3_mode() && !(training && !train_wino)) ? L.x3w : nullptr;
     a.bf16 = mfma_mode;
     Tensor o;
     if (batch_as_h) {
@@ -1038,7 +1044,7 @@ Model::SrcSpec Model::upsampled(const Tensor& t) {
     }
     static const bool fuse_on = !(getenv("VR_X3_FUSE_UP") && atoi(getenv("VR_X3_FUSE_UP")) == 0);
     static const bool x3_on = !(getenv("VR_CONV_X3") && atoi(getenv("VR_CONV_X3")) == 0);
-    if (fuse_on && x3_on && mfma_mode == 2 && 4LL * t.H * t.W >= 65536 && 2 * t.W >= 32 && !t.aff0 && !t.aff1 && !t.post && t.slope == 1.f) {
+    if (fuse_on && x3_on && x3_mode() && 4LL * t.H * t.W >= 65536 && 2 * t.W >= 32 && !t.aff0 && !t.aff1 && !t.post && t.slope == 1.f) {
         SrcSpec s{t};
         s.up = true;
         return s;
@@ -1784,6 +1790,11 @@ void Model::debug_conv(const float* x, int N, int Cin, int H, int W, const float
             a.wino6 = dwino6;
             VR_HIP(hipMalloc(&dx3w, x3_weights_bytes(Cin, 9, CoutPad)));
             launch_x3_weights(dw_, dx3w, Cin, 9, CoutPad, stream);
+            a.x3w = dx3w;
+        }
+        if (mfma_mode == 3) {
+            VR_HIP(hipMalloc(&dx3w, x3_weights_bytes(Cin, 9, CoutPad)));
+            launch_x3h_weights(dw_, dx3w, Cin, 9, CoutPad, stream);
             a.x3w = dx3w;
         }
     }

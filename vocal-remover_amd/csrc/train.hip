@@ -209,7 +209,7 @@ void Model::bwd_conv(TapeRec& r) {
     }
     {
         auto itx = x3t_of.find(L.w);
-        d.x3w = (!dry && train_wino && mfma_mode == 2 && itx != x3t_of.end()) ? itx->second : nullptr;
+        d.x3w = (!dry && train_wino && x3_mode() && itx != x3t_of.end()) ? itx->second : nullptr;
     }
     d.bias = nullptr;
     d.bf16 = mfma_mode;
@@ -746,6 +746,11 @@ void Model::debug_conv_bwd(const float* x, int N, int Cin, int H, int W, const f
         if (mfma_mode == 2) {
             VR_HIP(hipMalloc(&dx3t, x3_weights_bytes(Cout, 9, CinPad)));
             launch_x3_weights(dwt, dx3t, Cout, 9, CinPad, stream);
+            x3t_of[&P] = dx3t;
+        }
+        if (mfma_mode == 3) {
+            VR_HIP(hipMalloc(&dx3t, x3_weights_bytes(Cout, 9, CinPad)));
+            launch_x3h_weights(dwt, dx3t, Cout, 9, CinPad, stream);
             x3t_of[&P] = dx3t;
         }
     }
