@@ -18,17 +18,21 @@ cores, N=1 only).
 
 `roofline` is measured live: the fastest of THREE EXTRA steps after the timed region, run with every kernel serialised on one
 stream and EVERY kernel launch bracketed by HIP events on the stream it is launched on (vr_profile_begin / vr_profile_report).
-`roofline.classes` lists each kernel class against ITS OWN ceiling -- conv_x3 (3x3 stride-1, six bf16 products per fp32 product)
-against the bf16 matrix pipe (2500 TFLOP/s dense, achieved = 6 x the direct-convolution FLOPs / time), the fp32-MFMA convolutions
+`roofline.classes` lists each kernel class against ITS OWN ceiling -- conv_x3h (3x3 stride-1, three fp16 products per fp32 product:
+14 16-deep matrix instructions per 9 taps x 8 channels = 3.11 executed products per product) against the fp16 matrix pipe
+(2500 TFLOP/s dense, achieved = 3.11 x the direct-convolution FLOPs / time; conv_x3 of mfma_mode 2: 6 x), the fp32-MFMA convolutions
 and weight gradients against 157.3 TFLOP/s, the 1x1 / thin / element-wise / STFT kernels against 8 TB/s of HBM with their
 algorithmic bytes -- a class is priced against whichever of its two roofs (FLOPs / peak, bytes / 8 TB/s) is the longer time.
 `roofline.frac` is the DOMINANT class's own fraction; `frac_fp32_equivalent` keeps the round-1..3 aggregate (direct-conv FLOPs of
 the whole conv family / fp32-MFMA peak).  `roofline.kernels` carries the per-kernel rows the classes are summed from; the
 rocprofv3 summaries of the same command are in profiles/.  HBM traffic per launch comes from the committed rocprofv3 PMC passes.
 
-Arithmetic: fp32 throughout; the 3x3 stride-1 convolutions form every fp32 product from six bf16 products of three-way
-split operands on the bf16 matrix pipe (mfma_mode 2, the library default: error against fp64 = an fp32 direct
-convolution's).  `fp32_mfma` carries the same workloads with v_mfma_f32_32x32x2_f32 everywhere (mfma_mode 0).
+Arithmetic: fp32 storage, accumulation and results throughout; the 3x3 stride-1 convolutions (84 % of the multiply-adds) form
+every product from three fp16 products of two-way split, power-of-two scaled operands on the fp16 matrix pipe (mfma_mode 3, the
+library default since round 4: 22 significand bits per operand; measured error against fp64 at or below an fp32 direct
+convolution's, tests/test_gpu_parity.py / test_gpu_b16.py).  `split_bf16` carries the same workloads with six bf16 products of
+three-way split operands (mfma_mode 2, products exact to fp32; the round-3 default), `fp32_mfma` with v_mfma_f32_32x32x2_f32
+everywhere (mfma_mode 0).
 
 `python bench.py --gpus N` without a torch.distributed environment launches its own N ranks
 (python -m torch.distributed.run); under the driver's launcher it just reads RANK / WORLD_SIZE.
@@ -182,7 +186,8 @@ def cpu_baseline_train(sd, want_batch=16):
                       '(%.0f GB of host memory available; the GPU runs batch %d) -- %.1f s wall' % (B, mem, want_batch, dt)}
 
 
-SPLIT_DTYPE = 'f32 (3x3 stride-1 convs: bf16x3 split operands, six bf16 products per fp32 product, fp32 accumulate; rest: fp32 MFMA / VALU)'
+SPLIT_DTYPE = ('f32 (3x3 stride-1 convs: fp32 operands as two power-of-two scaled fp16 planes, three fp16 products per fp32 product on '
+               'v_mfma_f32_32x32x16_f16, fp32 accumulate -- error vs fp64 <= an fp32 direct convolution\'s; rest: fp32 MFMA / VALU)')
 
 
 def self_launch(args):
@@ -584,6 +589,10 @@ def main():
         f32_inf, _ = run_infer(False)
         try:
             f32_trn, _ = run_train(False, mfma_mode=0)
+            # ... and with the round-3 default: fp32 products from six bf16 products (mfma_mode 2, conv_x3.hip)
+            wl.set_mode(mfma_mode=2)
+            b16_inf, _ = run_infer(False)
+            b16_trn, _ = run_train(False, mfma_mode=2)
         finally:
             wl.set_mode(mfma_mode=-1)
         wl.end_train()
@@ -603,9 +612,9 @@ def main():
                 'value': c4_res['frames_per_sec'], 'ms_per_step': c4_res['ms_per_step'], 'steps': args.steps, 'warmup': args.warmup,
                 'global_batch': c4_res['global_batch'], 'workload': c4_res['workload'], 'parallelism': c4_res['parallelism'],
                 'ms_per_step_per_rank': c4_res['ms_per_step_per_rank'], 'allreduce_ms': c4_res['allreduce_ms'],
-                'dtype': 'bf16 where it is exact or harmless: the 3x3 stride-1 convolutions multiply on the bf16 matrix pipe (three-way split operands, '
-                         'six bf16 products per fp32 product: fp32-exact, mfma_mode 2) and the gradient bucket crosses xGMI in bf16 (rounded once, '
-                         'summed by RCCL in bf16, widened back); activations, master weights, accumulation and Adam stay fp32',
+                'dtype': '16-bit where it is exact or harmless: the 3x3 stride-1 convolutions multiply on the 16-bit matrix pipe (two-way split fp16 '
+                         'operands, three products per fp32 product: fp32-grade, mfma_mode 3) and the gradient bucket crosses xGMI in bf16 (rounded '
+                         'once, summed by RCCL in bf16, widened back); activations, master weights, accumulation and Adam stay fp32',
                 'what_it_is_not': 'a bf16-STORAGE pipeline: bf16 operands without the split lose the gradient direction on this net (cosine 0.37 vs fp32 at '
                                   'batch 16, tests/test_gpu_b16.py) and storing the three bf16 planes (6 B per element) measured no faster than fp32 storage '
                                   '(conv_x3p.hip, DESIGN.md section 3)',
@@ -613,12 +622,19 @@ def main():
                           'mfma_mode 0 with the fp32 bucket at batch 16'}
             out['fp32_mfma'] = {
                 'what': "vr_set_option('mfma_mode', 0): every convolution on v_mfma_f32_32x32x2_f32 / 16x16x4 (fp32 operands; Winograd "
-                        'F(2x2,3x3) for the 3x3 stride-1 layers, decoder upsample materialised) -- the default (mode 2) instead forms the '
-                        'fp32 products of those layers from six bf16 products on v_mfma_f32_32x32x16_bf16; both modes pass the same parity '
+                        'F(2x2,3x3) for the 3x3 stride-1 layers, decoder upsample materialised) -- the default (mode 3) instead forms the '
+                        'products of those layers from three fp16 products on v_mfma_f32_32x32x16_f16; all modes pass the same parity '
                         'tests at the same tolerances (tests/test_gpu_parity.py, test_gpu_configs.py, test_gpu_b16.py)',
                 'dtype': 'f32',
                 'infer': {'value': f32_inf['frames_per_sec'], 'ms_per_step': f32_inf['ms_per_step']},
                 'train': {'value': f32_trn['frames_per_sec'], 'ms_per_step': f32_trn['ms_per_step']}}
+            out['split_bf16'] = {
+                'what': "vr_set_option('mfma_mode', 2): the 3x3 stride-1 layers with fp32 products from SIX bf16 products of three-way split "
+                        'operands on v_mfma_f32_32x32x16_bf16 (conv_x3.hip; every product exact to fp32, 27 matrix instructions per 8-channel '
+                        'chunk where the default mode 3 issues 14) -- the round-3 default',
+                'dtype': 'f32',
+                'infer': {'value': b16_inf['frames_per_sec'], 'ms_per_step': b16_inf['ms_per_step']},
+                'train': {'value': b16_trn['frames_per_sec'], 'ms_per_step': b16_trn['ms_per_step']}}
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

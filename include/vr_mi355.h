@@ -59,12 +59,17 @@ int vr_get_param(vr_handle h, const char* key, void* host, int64_t capacity_byte
 int vr_set_mode(vr_handle h, int training);
 /* Numerical options.  "train_winograd" (default 1): train-mode forward and data-gradient 3x3 stride-1
  * convolutions may use the transformed-weight kernels (mfma_mode 0: Winograd F(2x2,3x3), fp32, rounding differs from the direct
- * kernel by ~1e-6 relative per conv -- the same class of difference as cuDNN's algorithm choice in the reference; mfma_mode 2, the
- * default: the split-bf16 direct kernel conv_x3.hip); 0 = the fp32 direct kernels only.  Eval follows "mfma_mode" alone.
+ * kernel by ~1e-6 relative per conv -- the same class of difference as cuDNN's algorithm choice in the reference; mfma_mode 3 / 2:
+ * the split direct kernels conv_x3h.hip / conv_x3.hip); 0 = the fp32 direct kernels only.  Eval follows "mfma_mode" alone.
  * "adam_reset": zero the Adam moments and the step counter (what constructing a new
  * torch.optim.Adam does; train.py:215-218).  "serial_exec" (default 0): 1 = every kernel on the handle's one
  * stream, no lanes / side streams (tests: results must not depend on the concurrent executor).
- * "mfma_mode" (default 2): how the 3x3 stride-1 convolutions (84 % of the multiply-adds) form their products.
+ * "mfma_mode" (default 3): how the 3x3 stride-1 convolutions (84 % of the multiply-adds) form their products.
+ *   3 = fp32-grade products from THREE fp16 products: every operand is scaled by an exact power of two (weights per output channel,
+ *       pixels per workgroup tile and 8-channel chunk, the accumulators follow) and written as two fp16 numbers (22 significand
+ *       bits), a*b ~= a1b1 + a1b2 + a2b1 with fp32 accumulation on v_mfma_f32_32x32x16_f16 -- conv_x3h.hip, forward and data
+ *       gradient, 14 matrix instructions per 8-channel chunk; measured error against fp64 at or below mode 2's and an fp32 direct
+ *       convolution's (tests), any fp32 dynamic range (2^+-100 scales, subnormals) included.
  *   2 = fp32 products assembled from six bf16 products of three-way split operands (x = x1 + x2 + x3 exactly,
  *       a*b = a1b1 + a2b1 + a1b2 + a2b2 + a1b3 + a3b1, fp32 accumulation) on v_mfma_f32_32x32x16_bf16 -- the direct kernel
  *       conv_x3.hip, forward and data gradient; error against fp64 = an fp32 direct convolution's (tests); in eval the
@@ -73,7 +78,7 @@ int vr_set_mode(vr_handle h, int training);
  *   0 = v_mfma_f32_32x32x2_f32 (fp32 operands) throughout: Winograd F(2x2,3x3) / direct kernels (the round-1/2 default).
  *   1 = bf16 MFMA operands (configs[4] arithmetic): the Winograd convolutions (forward, data gradient, weight gradient) and
  *       the 1x1 weight-gradient GEMM round their operands to bf16 (RNE, in registers); accumulation, every stored tensor, the
- *       master weights and Adam stay fp32.   -1 = back to the handle's default (2, or VR_MFMA_MODE).
+ *       master weights and Adam stay fp32.   -1 = back to the handle's default (3, or VR_MFMA_MODE).
  * "mfma_bf16": 1 = "mfma_mode" 1; 0 = back to the handle's default mode.
  * "params_dirty": the parameter arena was written from outside (vr_param_arena).
  * "hip_graph" (default 0, or VR_HIP_GRAPH): 1 = vr_separate_wave with device-resident input and outputs (and without

@@ -48,7 +48,7 @@ def _run(nat, h, name, spec):
     return out
 
 
-@pytest.mark.parametrize('mode', [2, 0], ids=['beside_conv_x3', 'beside_conv_wino'])
+@pytest.mark.parametrize('mode', [2, 3, 0], ids=['beside_conv_x3', 'beside_conv_x3h', 'beside_conv_wino'])
 def test_lds_consumers_are_bit_stable_beside_the_conv_kernels(vr, mode):
     nat = vr.native
     victim = vr.nets.CascadedNet(512, 256, 8, 32)

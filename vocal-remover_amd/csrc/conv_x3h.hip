@@ -85,7 +85,9 @@ struct X3hCfg {
     static constexpr int E_OFF = L_OFF + L_BYTES;               // epilogue constants of the cout tile: bias, scale, shift, 1 / weight scale [4][MT] fp32
     static constexpr int M_OFF = E_OFF + 4 * MT * 4;            // the four wave maxima of the chunk being split (uint bits of |x|)
     static constexpr int LDS_BYTES = M_OFF + 16;
-    static constexpr int OCC = (MT == 32 && TH == 8) ? 3 : 2;   // workgroups per CU the register budget must allow (conv_x3.hip's)
+    // workgroups per CU the register budget must allow (64 x 8 would fit three by LDS, 53 KB, but needs 175 registers: 36 bytes of
+    // scratch under a 168-register cap, and a spilled in-flight pixel register would be silently wrong)
+    static constexpr int OCC = (MT == 32 && TH == 8) ? 3 : 2;
     // vector-memory operations a wave issues per chunk: 8 * NPASS pixel loads (always, also beyond Cin: empty descriptor), and at
     // least NWMIN weight DMAs (the last wave-instruction of the weight slab may be empty for some waves)
     static constexpr int NXL = 8 * NPASS, NWMIN = (NWP / 64) / 4;

@@ -159,16 +159,17 @@ public:
     char* aug_buf = nullptr; size_t aug_cap = 0;         // staging of the training input pipeline
     bool train_wino = true;                              // vr_set_option("train_winograd"): Winograd kernels in train mode
     // vr_set_option("mfma_mode"): how the 3x3 stride-1 convs multiply.
-    //   2 (default) = fp32 products as six bf16 products of three-way split operands on v_mfma_f32_32x32x16_bf16, fp32 accumulation
+    //   2 (round-3 default) = fp32 products as six bf16 products of three-way split operands on v_mfma_f32_32x32x16_bf16, fp32 accumulation
     //       (conv_x3.hip: direct conv, error vs fp64 = an fp32 direct convolution's; forward and data-gradient convs -- weight
     //       gradients stay on the fp32 MFMA);
     //   0 = v_mfma_f32_32x32x2_f32 throughout (Winograd F(2x2,3x3) / direct kernels, round-1/2 default);
     //   1 = operands rounded to bf16 (configs[4] arithmetic; "mfma_bf16" 1 is the same);
-    //   3 = the layers of mode 2 with fp32-grade products from THREE fp16 products of two-way split, power-of-two scaled operands on
-    //       v_mfma_f32_32x32x16_f16 (conv_x3h.hip: 14 instead of 27 matrix instructions per 8-channel chunk).
-    int mfma_mode = 2;
+    //   3 (default since round 4) = the layers of mode 2 with fp32-grade products from THREE fp16 products of two-way split,
+    //       power-of-two scaled operands on v_mfma_f32_32x32x16_f16 (conv_x3h.hip: 14 instead of 27 matrix instructions per 8-channel
+    //       chunk; measured error vs fp64 at or below mode 2's).
+    int mfma_mode = 3;
     bool x3_mode() const { return mfma_mode == 2 || mfma_mode == 3; }
-    int default_mfma_mode = 2;                           // (VR_MFMA_MODE overrides; "mfma_mode" -1 / "mfma_bf16" 0 return to it)
+    int default_mfma_mode = 3;                           // (VR_MFMA_MODE overrides; "mfma_mode" -1 / "mfma_bf16" 0 return to it)
     bool serial = false;                                 // vr_set_option("serial_exec"): no lanes / side streams (tests: race detector)
     void set_option(const std::string& name, int value);
     void reset_adam_state();

@@ -380,7 +380,7 @@ void Model::set_option(const std::string& name, int value) {
     else if (name == "serial_exec") serial = value != 0;     // every kernel on the handle's one stream (race detector of the tests)
     else if (name == "params_dirty") affine_dirty = true;    // the parameter arena was written from outside (vr_param_arena)
     else if (name == "mfma_bf16") { mfma_mode = value != 0 ? 1 : default_mfma_mode; affine_dirty = true; }   // bf16 operands on the matrix pipe (0: back to the handle's default mode)
-    else if (name == "mfma_mode") {                          // 0 fp32 MFMA, 1 bf16 operands, 2 fp32 via 6 bf16 products (model.h); -1 = the default
+    else if (name == "mfma_mode") {                          // 0 fp32 MFMA, 1 bf16 operands, 2 fp32 via 6 bf16 products, 3 via 3 fp16 products (model.h); -1 = the default
         if (value < -1 || value > 3) throw Error(-2, "mfma_mode: 0, 1, 2, 3 or -1 (default)");
         mfma_mode = value < 0 ? default_mfma_mode : value; affine_dirty = true;   // (the next eval forward refreshes the derived weight copies)
     }
