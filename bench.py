@@ -66,6 +66,7 @@ KERNEL_CLASSES = (
     ('conv_x3h_kernel', 'conv_x3h: 3x3 stride-1 forward + data gradient, fp32-grade products from three fp16 products (mfma_mode 3)', 'f16x3'),
     ('conv_x3b_kernel', 'conv_x3: 3x3 stride-1 forward + data gradient, fp32 products from six bf16 products', 'bf16'),
     ('conv_x3p_kernel', 'conv_x3p: 3x3 stride-1 over bf16-plane tensors (option conv_x3p), fp32 products from six bf16 products', 'bf16'),
+    ('wgrad_x3h_kernel', 'wgrad_x3h: 3x3 stride-1 weight gradient, direct form, fp32-grade products from three fp16 products (mfma_mode 3)', 'f16w'),
     ('wgrad_wino_', 'wgrad_wino: 3x3 stride-1 weight gradient, Winograd F(3x3,2x2), fp32 MFMA', 'fp32'),
     ('conv_wino_kernel', 'conv_wino: 3x3 stride-1, Winograd F(2x2,3x3), fp32 MFMA (mfma_mode 0)', 'fp32'),
     ('conv_dma_kernel<1,', 'conv 1x1 (ASPP, tails, LSTM projection / dense), fp32 MFMA', 'fp32'),
@@ -227,8 +228,9 @@ def roofline_from_rows(rows, pmc_name, conv_totals):
     for c in classes.values():
         ms, pipe = c['ms_per_step'], c.pop('pipe')
         # executed products per fp32 product: six on the bf16 pipe (conv_x3); conv_x3h issues 14 16-deep instructions per 9 taps x 8 channels
-        mult = {'bf16': 6.0, 'f16x3': 14 * 16 / 72.0}.get(pipe, 1.0)
-        pk = {'bf16': BF16_MFMA_PEAK_TFLOPS, 'f16x3': BF16_MFMA_PEAK_TFLOPS, 'fp32': FP32_MFMA_PEAK_TFLOPS}.get(pipe)
+        # (wgrad_x3h: three instructions per 16 pixels, tap and 32 x 32 block = 3 executed products per product)
+        mult = {'bf16': 6.0, 'f16x3': 14 * 16 / 72.0, 'f16w': 3.0}.get(pipe, 1.0)
+        pk = {'bf16': BF16_MFMA_PEAK_TFLOPS, 'f16x3': BF16_MFMA_PEAK_TFLOPS, 'f16w': BF16_MFMA_PEAK_TFLOPS, 'fp32': FP32_MFMA_PEAK_TFLOPS}.get(pipe)
         t_flop = (mult * c['flops'] / (pk * 1e12) * 1e3) if pk else 0.0          # ms at the matrix-pipe peak
         t_byte = c['bytes'] / (HBM_PEAK_TBS * 1e12) * 1e3                         # ms at the HBM peak
         if pipe == 'none' or ms <= 0 or (t_flop == 0 and t_byte == 0):
@@ -236,6 +238,7 @@ def roofline_from_rows(rows, pmc_name, conv_totals):
         elif t_flop >= t_byte:
             c.update({'bound': 'mfma', 'pipe': 'bf16 matrix pipe (v_mfma_f32_32x32x16_bf16), 6 executed products per fp32 product' if pipe == 'bf16'
                       else 'fp16 matrix pipe (v_mfma_f32_32x32x16_f16, same dense peak as bf16), 3.11 executed products per fp32 product' if pipe == 'f16x3'
+                      else 'fp16 matrix pipe (v_mfma_f32_32x32x16_f16), 3 executed products per fp32 product' if pipe == 'f16w'
                       else 'fp32 matrix pipe (v_mfma_f32_32x32x2_f32 / 16x16x4)', 'peak': pk, 'unit': 'TFLOP/s',
                       'achieved': mult * c['flops'] / (ms * 1e-3) / 1e12, 'frac': t_flop / ms})
         else:

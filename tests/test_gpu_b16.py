@@ -190,7 +190,7 @@ def test_b16_bf16_mode_vs_fp32_mode(vr, full16):
     assert gcos1 >= 0.2 and 0.95 <= gratio1 <= 1.05
 
 
-SPECIAL = ['subnormal', 'scale_2^-100', 'scale_2^+100', 'bf16_boundaries']
+SPECIAL = ['subnormal', 'scale_2^-100', 'scale_2^+100', 'bf16_boundaries', 'chunk_scales']
 
 
 @pytest.mark.parametrize('kind', SPECIAL)
@@ -212,6 +212,11 @@ def test_split_bf16_mode_is_fp32_exact_on_special_values(vr, full16, kind, shape
         x = (x * np.float32(2.0 ** -100)).astype(np.float32)
     elif kind == 'scale_2^+100':
         x = (x * np.float32(2.0 ** 100)).astype(np.float32)
+    elif kind == 'chunk_scales':
+        # every 8-channel chunk and every 8-row band at its own power of two (2^-40 .. 2^+40), weights per cout likewise: the running
+        # shift of conv_x3h.hip has to move up AND down inside one workgroup, and the per-cout weight scale covers 80 binades
+        x = x * (2.0 ** rng.integers(-40, 41, size=(1, (Cin + 7) // 8, (H + 7) // 8, 1))).repeat(8, 1)[:, :Cin].repeat(8, 2)[:, :, :H].astype(np.float32)
+        w = (w * (2.0 ** rng.integers(-40, 41, size=(Cout, 1, 1, 1)))).astype(np.float32)
     else:
         u = x.view(np.uint32).copy()
         r = rng.integers(0, 5, size=x.shape)
@@ -224,9 +229,10 @@ def test_split_bf16_mode_is_fp32_exact_on_special_values(vr, full16, kind, shape
         w = np.where(rng.random(w.shape) < 0.5, (wu & 0xffffff00) | 0x80, wu).astype(np.uint32).view(np.float32)
     want = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), None, 1, 1).numpy()
     cpu32 = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), None, 1, 1).numpy()
-    scale = float(np.abs(want).max())
+    # (chunk_scales: one scale per output channel, the weights of different couts differ by up to 2^80)
+    scale = np.abs(want).max(axis=(0, 2, 3), keepdims=True) if kind == 'chunk_scales' else float(np.abs(want).max())
     nat = vr.native
-    errs = {'torch cpu fp32': float(np.abs(cpu32.astype(np.float64) - want).max()) / scale}
+    errs = {'torch cpu fp32': float((np.abs(cpu32.astype(np.float64) - want) / scale).max())}
     # fp32-MFMA direct kernel (mode 0, plain weights), fp32-MFMA Winograd (mode 0, transformed weights), split-bf16 direct (mode 2)
     for key, mode, flags in (('fp32 MFMA direct', 0, 0), ('fp32 MFMA Winograd', 0, 2), ('split-bf16', 2, 2), ('split-fp16', 3, 2)):
         got = np.empty(want.shape, np.float32)
@@ -237,7 +243,7 @@ def test_split_bf16_mode_is_fp32_exact_on_special_values(vr, full16, kind, shape
         finally:
             model.set_option('mfma_mode', -1)
         assert np.isfinite(got).all()
-        errs[key] = float(np.abs(got.astype(np.float64) - want).max()) / scale
+        errs[key] = float((np.abs(got.astype(np.float64) - want) / scale).max())
     print('%s %s: max error / scale  ' % (kind, shape) + '  '.join('%s %.3e' % kv for kv in errs.items()))
     # as exact as an fp32 DIRECT convolution (the Winograd form sums 2.25x fewer products and sits below all of them)
     assert errs['split-bf16'] <= 1.5 * max(errs['fp32 MFMA direct'], errs['torch cpu fp32']) + 1e-7

@@ -56,10 +56,10 @@ __device__ __forceinline__ f32x16 mfma_f16x16(vr_f16x8 a, vr_f16x8 b, f32x16 c) 
 }
 // (x0, x1) * s -> packed fp16 pairs of the two planes: p1 = rne(x s), p2 = rne(x s - p1); each is ONE fp32 fma rounded once to fp16
 __device__ __forceinline__ void split2h_pair(float x0, float x1, float s, int& p1, int& p2) {
-    int a = 0, b = 0;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(a) : "v"(x0), "v"(s));
+    int a, b;                                    // (mixlo leaves the other half of its destination alone; mixhi then fills it: "=v" first)
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(a) : "v"(x0), "v"(s));
     asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(a) : "v"(x1), "v"(s));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "+v"(b) : "v"(x0), "v"(s), "v"(a));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=&v"(b) : "v"(x0), "v"(s), "v"(a));
     asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(b) : "v"(x1), "v"(s), "v"(a));
     p1 = a; p2 = b;
 }
@@ -95,8 +95,10 @@ struct X3hCfg {
     static_assert(TH % 4 == 0 && MT % 32 == 0 && LDS_BYTES <= 80 * 1024 && 2 * NXL + NWMIN < 64 && NXL <= 30 && LSLOT <= 256, "tile");
 };
 
-template <int MT, int TH>
-__global__ __launch_bounds__(256, (X3hCfg<MT, TH>::OCC)) void conv_x3h_kernel(const ConvArgs a) {
+// UP: some source arrives through the fused bilinear x2 (eval); the plain instantiation sheds that path's registers and code
+// HI: one more workgroup per CU than the register budget of the UP form allows (plain form only: 153 / 113 registers)
+template <int MT, int TH, bool UP, bool HI>
+__global__ __launch_bounds__(256, (X3hCfg<MT, TH>::OCC + (HI ? 1 : 0))) void conv_x3h_kernel(const ConvArgs a) {
     using Cfg = X3hCfg<MT, TH>;
     constexpr int TW = Cfg::TW, KK = Cfg::KK, PW = Cfg::PW, NSLOT = Cfg::NSLOT, NPASS = Cfg::NPASS, WM = Cfg::WM, WN = Cfg::WN,
                   PLANE = Cfg::PLANE, NWP = Cfg::NWP, NWPASS = Cfg::NWPASS;
@@ -127,22 +129,20 @@ __global__ __launch_bounds__(256, (X3hCfg<MT, TH>::OCC)) void conv_x3h_kernel(co
     const unsigned lds0 = (unsigned)(size_t)smem_x3h;
     const int dbg = a.dbg & 15;
 
-    // ---- this thread's pixels of the halo tile: byte offset in a channel plane = hrow * (4 * sH) + wcol4 (2^31: padding) ----
-    unsigned hrow[NPASS], wcol4[NPASS];
-#pragma unroll
-    for (int p = 0; p < NPASS; ++p) {
+    // ---- this thread's pixels of the halo tile: byte offset in a channel plane = row * (4 * sH) + 4 * column (2^31: padding);
+    // recomputed from the thread index whenever the source (= the row pitch) changes, instead of held in registers ----
+    auto pixel_offset = [&](int p, unsigned sH4) -> int {
         const int s = p * 256 + tid;
         const int r = s / PW, c = s - r * PW;
         const int hi = h0 - 1 + r, wi = w0 - 1 + c;
         const bool ok = s < NSLOT && hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win;
-        hrow[p] = ok ? (unsigned)hi : 0u;
-        wcol4[p] = ok ? (unsigned)(wi * 4) : 0x80000000u;
-    }
+        return ok ? (int)((unsigned)hi * sH4 + (unsigned)(wi * 4)) : (int)0x80000000u;
+    };
     // ---- sources that arrive through the decoder's bilinear x2 (align_corners=True; eval: the upsample is not materialised):
     // this thread's low-resolution pixel of the staging tile, and for each of its halo pixels the position inside that tile
     // and the two interpolation weights (upsampled sources share their geometry: model.hip) ----
     const ConvSrc& us = a.src[0].up ? a.src[0] : (a.src[1].up ? a.src[1] : a.src[2]);
-    const bool any_up = a.src[0].up | a.src[1].up | a.src[2].up;
+    constexpr bool any_up = UP;
     int lrow = 0, lcol4 = 0;                       // low-res pixel this thread fetches (byte column; 2^31: none)
     int lidx[NPASS];
     float lh[NPASS], lw_[NPASS];
@@ -166,13 +166,15 @@ __global__ __launch_bounds__(256, (X3hCfg<MT, TH>::OCC)) void conv_x3h_kernel(co
         }
     }
     // ---- weight operands: LDS order [tap][plane][m], source x3w[chunk][(tap * 2 + plane) * CoutPad + co0 + m] ----
-    unsigned woff[NWPASS];
-#pragma unroll
-    for (int i = 0; i < NWPASS; ++i) {
-        const int q = (wave + 4 * i) * 64 + lane;
+    // (lane q = (wave + 4 i) * 64 + lane covers operand (tp, m) = (q / MT, q % MT): the part that depends on the pass i is the same
+    // for every lane, so it rides on the scalar offset of the DMA -- one vector offset instead of NWPASS)
+    unsigned woff0;
+    {
+        const int q = wave * 64 + lane;
         const int m = q % MT, tp = q / MT;
-        woff[i] = (unsigned)((tp * a.CoutPad + m) * 16);
+        woff0 = (unsigned)((tp * a.CoutPad + m) * 16);
     }
+    const unsigned wstep = (unsigned)((256 / MT) * a.CoutPad * 16);   // four waves further on
     const long long wchunk_bytes = (long long)KK * 2 * a.CoutPad * 16;
     auto issue_w = [&](int k) {                                    // the weight DMA of chunk k: NWPASS wave-instructions
         const char* wb = static_cast<const char*>(a.x3w) + k * wchunk_bytes + (long long)co0 * 16;
@@ -181,8 +183,8 @@ __global__ __launch_bounds__(256, (X3hCfg<MT, TH>::OCC)) void conv_x3h_kernel(co
 #pragma unroll
         for (int i = 0; i < NWPASS; ++i) {
             const int pp = wave + 4 * i;
-            if ((pp + 1) * 64 <= NWP) dma16(ws_b + pp * 1024, woff[i], wr);
-            else if (pp * 64 + lane < NWP) dma16(ws_b + pp * 1024, woff[i], wr);
+            if ((pp + 1) * 64 <= NWP) dma16s(ws_b + pp * 1024, woff0, wr, (unsigned)i * wstep);
+            else if (pp * 64 + lane < NWP) dma16s(ws_b + pp * 1024, woff0, wr, (unsigned)i * wstep);
         }
     };
     // The channels are visited strictly in order (chunk by chunk), so the source of the virtual concat is a running scalar
@@ -195,13 +197,13 @@ __global__ __launch_bounds__(256, (X3hCfg<MT, TH>::OCC)) void conv_x3h_kernel(co
     unsigned upm[2] = {0u, 0u};                                    // per pixel-register set: which of the 8 channels are upsampled sources
     int xvo[NPASS];                                                // byte offset of this thread's pixels in a channel plane of the current source
 #pragma unroll
-    for (int p = 0; p < NPASS; ++p) xvo[p] = (int)(hrow[p] * xsH4 + wcol4[p]);
+    for (int p = 0; p < NPASS; ++p) xvo[p] = pixel_offset(p, xsH4);
     auto next_source = [&]() {
         ++xsi;
         if (xsi == 1) { xp = a.src[1].p + (long long)n * a.src[1].sN; xsC = a.src[1].sC; xsH4 = (unsigned)a.src[1].sH * 4u; xend = a.c2; xup = a.src[1].up != 0; }
         else { xp = a.src[2].p + (long long)n * a.src[2].sN; xsC = a.src[2].sC; xsH4 = (unsigned)a.src[2].sH * 4u; xend = 1 << 30; xup = a.src[2].up != 0; }
 #pragma unroll
-        for (int p = 0; p < NPASS; ++p) xvo[p] = (int)(hrow[p] * xsH4 + wcol4[p]);
+        for (int p = 0; p < NPASS; ++p) xvo[p] = pixel_offset(p, xsH4);
     };
     // Pixel registers of two chunks: the loads of chunk k+2 are issued during the multiply phase of chunk k and consumed at the end of
     // the multiply phase of chunk k+1 -- one multiply phase (1.4 us of matrix-pipe time) is shorter than the loaded memory latency.
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256, (X3hCfg<MT, TH>::OCC)) void conv_x3h_kernel(co
         if (live && ci >= xend) next_source();                    // (a source may be a single channel: two steps at most)
         if (live && ci >= xend) next_source();
         const i32x4 xs = make_rsrc(xp, live ? 0x7FFFFFF0u : 0u);
-        const bool up = live && xup;
+        const bool up = UP && live && xup;
         if (cl == 0) upm[PAR] = 0u;
         upm[PAR] |= (up ? 1u : 0u) << cl;
         // an upsampled source: ONE low-resolution pixel per thread (register set 0 of the channel); the other sets load nothing
@@ -598,15 +600,23 @@ void launch_x3h_weights_batched(const X3WDesc* d_descs, int n, long long max_ele
     VR_HIP(hipGetLastError());
 }
 
-template <int MT, int TH>
-static void x3h_launch(const ConvArgs& a, hipStream_t st) {
+template <int MT, int TH, bool UP, bool HI>
+static void x3h_launch_up(const ConvArgs& a, hipStream_t st) {
     using Cfg = X3hCfg<MT, TH>;
-    auto kern = conv_x3h_kernel<MT, TH>;
+    auto kern = conv_x3h_kernel<MT, TH, UP, HI>;
     static std::atomic<unsigned long long> attr_done{0};
     ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
     const int groups = (a.npt + 7) / 8;
     VR_LAUNCH(kern, dim3(groups * 8 * a.nct), dim3(256), Cfg::LDS_BYTES, st, a);
     VR_HIP(hipGetLastError());
+}
+
+template <int MT, int TH>
+static void x3h_launch(const ConvArgs& a, hipStream_t st) {
+    static const int hi = [] { const char* e = getenv("VR_X3H_HI"); return e ? atoi(e) : 0; }();
+    if (a.src[0].up | a.src[1].up | a.src[2].up) x3h_launch_up<MT, TH, true, false>(a, st);
+    else if (hi && TH == 8) x3h_launch_up<MT, TH, false, (TH == 8)>(a, st);
+    else x3h_launch_up<MT, TH, false, false>(a, st);
 }
 
 // same tile choice as conv_x3.hip (x3_pick / x3_fill_tiling); taken when ConvArgs::bf16 == 3

@@ -29,6 +29,12 @@ __device__ __forceinline__ void dma16(unsigned lds_base, unsigned voff, i32x4 rs
                  :: "s"(lds_base), "v"(voff), "s"(rsrc) : "memory");
 }
 
+// The same with a scalar byte offset added to every lane's address (not part of the range check: gfx9 compares the vector offset).
+__device__ __forceinline__ void dma16s(unsigned lds_base, unsigned voff, i32x4 rsrc, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
 // Dword form: lane l copies 4 B to LDS byte lds_base + 4*l (any 4-B aligned base: odd LDS pitches stay possible).
 __device__ __forceinline__ void dma4(unsigned lds_base, unsigned voff, i32x4 rsrc) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"

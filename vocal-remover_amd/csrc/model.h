@@ -240,6 +240,10 @@ private:
     // vr_set_option("conv_x3p"): -1 = the default (VR_CONV_X3P, else OFF: measured no faster than conv_x3.hip and its producers cost
     // more than the split pass they replace -- DESIGN.md section 3), 0 off, 1 on
     int x3p_opt = -1;
+    // vr_set_option("wgrad_x3h"): mfma_mode 3 only -- the 3x3 stride-1 weight gradients in the direct three-fp16-product form
+    // (wgrad_x3h.hip) instead of Winograd on the fp32 pipe.  Default OFF (VR_WGRAD_X3H=1 turns it on): correct and as exact, but no faster
+    int wgrad_x3h_opt = -1;
+    bool wgrad_x3h_on() const;
     bool x3p_on() const { return !training && mfma_mode == 2 && (x3p_opt < 0 ? x3p_enabled() : x3p_opt != 0); }
     // batched refresh: descriptor tables (host copy + device copy, re-uploaded only when a pointer changed)
     struct WinoBatch { std::vector<WinoWDesc> host; WinoWDesc* dev = nullptr; long long max_elems = 0; };

@@ -384,6 +384,7 @@ void Model::set_option(const std::string& name, int value) {
         if (value < -1 || value > 3) throw Error(-2, "mfma_mode: 0, 1, 2, 3 or -1 (default)");
         mfma_mode = value < 0 ? default_mfma_mode : value; affine_dirty = true;   // (the next eval forward refreshes the derived weight copies)
     }
+    else if (name == "wgrad_x3h") { wgrad_x3h_opt = value < 0 ? -1 : (value != 0); }
     else if (name == "conv_x3p") { x3p_opt = value < 0 ? -1 : (value != 0); affine_dirty = true; }   // eval: 3x3 stride-1 convs over bf16-plane tensors (conv_x3p.hip)
     else if (name == "adam_reset") reset_adam_state();      // a freshly constructed torch.optim.Adam has no moments
     else throw Error(-2, "unknown option: " + name);
@@ -482,6 +483,11 @@ void Model::refresh_wino(bool with_dgrad) {
         if (it != wt_of.end()) d.push_back(WinoWDesc{it->second, winot_of[L->w], L->Cout, cin_pad(L)});
     }
     run_wino_batch(wb_bwd, d, false);
+}
+
+bool Model::wgrad_x3h_on() const {
+    static const bool env = [] { const char* e = getenv("VR_WGRAD_X3H"); return e && atoi(e) != 0; }();
+    return mfma_mode == 3 && (wgrad_x3h_opt < 0 ? env : wgrad_x3h_opt != 0);
 }
 
 void Model::run_x3_batch(X3Batch& b, std::vector<X3WDesc>& descs) {

@@ -185,6 +185,7 @@ struct WgradArgs {
     int dma;                   // 1: every source is a plain tensor -> the loader waves use LDS-DMA (no arithmetic)
     int bf16;                  // 1: bf16 MFMA operands (wgrad_wino.hip, wgrad_gemm.hip)
     int allow_wino;            // 1: 3x3 stride-1 layers with plain inputs may take the Winograd F(3x3,2x2) kernel (wgrad_wino.hip)
+    int x3h;                   // 1 (with bf16 == 3): ... or the direct three-fp16-product kernel (wgrad_x3h.hip; option "wgrad_x3h", default off)
 };
 double launch_wgrad(const WgradArgs& a, const ConvShape& s, float* grad_out, int accumulate, hipStream_t st);
 size_t wgrad_scratch_floats(const WgradArgs& a, const ConvShape& s);
