@@ -4,6 +4,7 @@
 // BatchNorm affine + ReLU/LeakyReLU, the Dropout2d keep-mask, conv zero padding, and -- for the
 // data-gradient of stride-2 convs -- zero insertion between the elements of the incoming gradient.
 #pragma once
+#include <type_traits>
 #include "vr_common.h"
 
 namespace vr {
@@ -59,6 +60,23 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, int& p1, int& p2
 }
 __device__ __forceinline__ f32x16 mfma_bf16x16(vr_bf16x8 a, vr_bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// Sum over the 32 lanes that share lane >> 5 (one accumulator row of a 32x32 MFMA tile), DPP only: quad swaps, row_half_mirror and
+// row_mirror leave every lane of a row of 16 with the row's sum, row_bcast:15 adds the lower row's into the upper one -- the total is
+// valid in lanes 16-31 and 48-63 ((lane & 16) != 0).  Five VALU instructions; __shfl_xor is a ds_bpermute (an LDS instruction with
+// its own latency) per step: 320 of them per workgroup tile in the BatchNorm partial sums of a 64-cout training conv.
+__device__ __forceinline__ float half_wave_sum_dpp(float v) {
+    auto step = [](float x, auto ctrl, auto rmask) {
+        constexpr int C = decltype(ctrl)::value, R = decltype(rmask)::value;
+        return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), C, R, 0xF, true));
+    };
+    v = step(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xF>{});     // quad_perm [1,0,3,2]
+    v = step(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xF>{});     // quad_perm [2,3,0,1]
+    v = step(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xF>{});    // row_half_mirror
+    v = step(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xF>{});    // row_mirror
+    v = step(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});    // row_bcast:15 into rows 1 and 3
+    return v;
 }
 
 // Fields of a.src[si] for a wave-uniform si, selected one by one with scalar selects: indexing the

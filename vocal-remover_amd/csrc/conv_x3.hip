@@ -407,12 +407,9 @@ __global__ __launch_bounds__(256, (X3Cfg<MT, TH>::OCC)) void conv_x3_kernel(cons
                         s2 = fmaf(v, v, s2);
                     }
                 }
-#pragma unroll
-                for (int off = 16; off >= 1; off >>= 1) {
-                    s1 += __shfl_xor(s1, off, 64);
-                    s2 += __shfl_xor(s2, off, 64);
-                }
-                if (l31 == 0) {
+                s1 = half_wave_sum_dpp(s1);
+                s2 = half_wave_sum_dpp(s2);
+                if (l31 == 16) {                                   // (the sums are complete in lanes 16-31 / 48-63)
                     const int m = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
                     red[(wave * MT + m) * 2 + 0] = s1;
                     red[(wave * MT + m) * 2 + 1] = s2;
