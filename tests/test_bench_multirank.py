@@ -99,6 +99,30 @@ def test_roofline_classes_price_each_kernel_against_its_own_roof():
     assert r['traffic'] is None and len(r['kernels']) == 5
 
 
+def test_every_conv_and_wgrad_kernel_of_the_library_has_a_matrix_pipe_class():
+    """A conv / weight-gradient kernel that bench.classify() does not know would be priced as an HBM streaming kernel and could become
+    the 'dominant class' with a meaningless fraction (round 4: wgrad_wino_r_kernel and conv_x3p_kernel did exactly that once).  The
+    kernel names come from the built library's host stubs."""
+    import shutil
+    sys.path.insert(0, ROOT)
+    import bench
+    import __graft_entry__
+    if not os.path.exists(__graft_entry__.LIB):
+        __graft_entry__.build()
+    nm = shutil.which('nm') or '/opt/rocm/lib/llvm/bin/llvm-nm'
+    out = subprocess.run([nm, '-C', __graft_entry__.LIB], capture_output=True, text=True).stdout
+    names = sorted({ln.split('__device_stub__', 1)[1].split('(')[0] for ln in out.splitlines() if '__device_stub__' in ln})
+    assert len(names) > 100, len(names)
+    # (wgrad_reduce_kernel sums partial slabs: a streaming kernel, not a multiply)
+    mac = [n for n in names if n.startswith(('conv_', 'wgrad_')) and 'weights' not in n and n != 'wgrad_reduce_kernel']
+    assert any(n.startswith('conv_x3h_kernel') for n in mac) and any(n.startswith('wgrad_wino_r_kernel') for n in mac)
+    missing = [n for n in mac if bench.classify('vr::' + n)[1] not in ('bf16', 'f16x3', 'f16w', 'fp32')]
+    assert not missing, missing
+    # ... and nothing else is claimed by a matrix-pipe class
+    wrong = [n for n in names if n not in mac and bench.classify('vr::' + n)[0] is not None]
+    assert not wrong, wrong
+
+
 COMM_PROBE = r'''
 import ctypes, json, sys
 sys.path.insert(0, sys.argv[1])
