@@ -425,6 +425,48 @@ __global__ __launch_bounds__(256) void thin_dgrad_kernel(Tensor x, const float* 
     *q = accumulate ? *q + v : v;
 }
 
+// float4 form (round 4): one thread = four consecutive columns x 8 channels; dz is fetched once per eight channels instead of once per
+// element, the three 64-bit divisions per element are gone (the scalar form above ran at 1.2-2.4 TB/s: 445 us for the head's 2 -> 32
+// data gradient at batch 16); rows must be 16-byte aligned.
+template <int CO>
+__global__ __launch_bounds__(256) void thin_dgrad4_kernel(Tensor x, const float* __restrict__ w, const float* __restrict__ dz,
+                                                          float* __restrict__ g, int accumulate) {
+    const int W4 = x.W >> 2;
+    const int total4 = x.N * x.H * W4;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= total4) return;
+    const int c0 = blockIdx.y * 8;
+    const int w4 = e % W4;
+    const int t = e / W4;
+    const int h = t % x.H;
+    const int n = t / x.H;
+    float4 d[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) d[o] = *reinterpret_cast<const float4*>(dz + (((long long)n * CO + o) * x.H + h) * x.W + 4 * w4);
+    float* gb = g + (long long)n * x.sN + (long long)h * x.sH + 4 * w4;
+    float4 old[8];
+    if (accumulate) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = c0 + k < x.C ? c0 + k : x.C - 1;
+            old[k] = *reinterpret_cast<const float4*>(gb + (long long)c * x.sC);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = c0 + k;
+        if (c < x.C) {
+            float4 v = accumulate ? old[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int o = 0; o < CO; ++o) {
+                const float wv = w[o * x.C + c];
+                v.x = fmaf(wv, d[o].x, v.x); v.y = fmaf(wv, d[o].y, v.y); v.z = fmaf(wv, d[o].z, v.z); v.w = fmaf(wv, d[o].w, v.w);
+            }
+            *reinterpret_cast<float4*>(gb + (long long)c * x.sC) = v;
+        }
+    }
+}
+
 template <int CO>
 __global__ __launch_bounds__(256) void thin_wgrad_kernel(Tensor x, const float* __restrict__ dz, float* __restrict__ part) {
     const int c0 = blockIdx.y * 8;
@@ -569,7 +611,14 @@ void launch_thin_dgrad(const Tensor& x, int CO, const float* w, const float* dz,
     const unsigned grid = (unsigned)((total + 255) / 256);
     // reads x (activation derivative), dz; writes (accumulating: read-modify-writes) g
     prof_note(2.0 * CO * (double)total, 4.0 * ((accumulate ? 3.0 : 2.0) * (double)total + (double)CO * x.N * x.H * x.W));
-    if (CO == 1) VR_LAUNCH((thin_dgrad_kernel<1>), dim3(grid), dim3(256), 0, st, x, w, dz, g, accumulate);
+    const bool vec = (x.W & 3) == 0 && (x.sH & 3) == 0 && (x.sC & 3) == 0 && (x.sN & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dz)) & 15) == 0 &&
+                     (long long)x.N * x.H * x.W < 0x7FFFFFFFLL;
+    if (vec) {
+        const dim3 g4((unsigned)(((long long)x.N * x.H * (x.W >> 2) + 255) / 256), (unsigned)((x.C + 7) / 8));
+        if (CO == 1) VR_LAUNCH((thin_dgrad4_kernel<1>), g4, dim3(256), 0, st, x, w, dz, g, accumulate);
+        else VR_LAUNCH((thin_dgrad4_kernel<2>), g4, dim3(256), 0, st, x, w, dz, g, accumulate);
+    } else if (CO == 1) VR_LAUNCH((thin_dgrad_kernel<1>), dim3(grid), dim3(256), 0, st, x, w, dz, g, accumulate);
     else VR_LAUNCH((thin_dgrad_kernel<2>), dim3(grid), dim3(256), 0, st, x, w, dz, g, accumulate);
     VR_HIP(hipGetLastError());
 }

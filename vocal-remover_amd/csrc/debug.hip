@@ -190,7 +190,8 @@ void Model::debug_kernel(const std::string& name, const int64_t* dims, int ndims
         t.slope = fp[0];
         if (in[1]) t.aff0 = aff.p;
         DevBuf part((size_t)thin_wgrad_blocks(t) * CO * C);
-        launch_thin_dgrad(t, CO, w.p, dz.p, g.p, 0, st);
+        launch_thin_dgrad(t, CO, w.p, dz.p, g.p, 0, st);          // store, then accumulate once more: the caller expects 2 x the gradient
+        launch_thin_dgrad(t, CO, w.p, dz.p, g.p, 1, st);
         launch_thin_wgrad(t, CO, dz.p, part.p, dw.p, 0, st);
         DevBuf zf((size_t)N * H * W);
         if (CO == 1) launch_squeeze_conv(t, w.p, zf.p, nullptr, false, st);
