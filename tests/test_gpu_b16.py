@@ -190,7 +190,7 @@ def test_b16_bf16_mode_vs_fp32_mode(vr, full16):
     assert gcos1 >= 0.2 and 0.95 <= gratio1 <= 1.05
 
 
-SPECIAL = ['subnormal', 'scale_2^-100', 'scale_2^+100', 'bf16_boundaries', 'chunk_scales']
+SPECIAL = ['subnormal', 'scale_2^-100', 'scale_2^+100', 'bf16_boundaries', 'chunk_scales', 'descending_chunks']
 
 
 @pytest.mark.parametrize('kind', SPECIAL)
@@ -217,6 +217,10 @@ def test_split_bf16_mode_is_fp32_exact_on_special_values(vr, full16, kind, shape
         # shift of conv_x3h.hip has to move up AND down inside one workgroup, and the per-cout weight scale covers 80 binades
         x = x * (2.0 ** rng.integers(-40, 41, size=(1, (Cin + 7) // 8, (H + 7) // 8, 1))).repeat(8, 1)[:, :Cin].repeat(8, 2)[:, :, :H].astype(np.float32)
         w = (w * (2.0 ** rng.integers(-40, 41, size=(Cout, 1, 1, 1)))).astype(np.float32)
+    elif kind == 'descending_chunks':
+        # chunk after chunk 2^50 smaller (2^40 ... 2^-120 and below): the running shift of conv_x3h.hip wants to follow, but the
+        # accumulators still hold the first chunk's sums -- it may not run more than 2^64 ahead of the largest chunk (overflow)
+        x = (x * (2.0 ** np.clip(40 - 50 * np.arange((Cin + 7) // 8), -125, 40)).reshape(1, -1, 1, 1).repeat(8, 1)[:, :Cin]).astype(np.float32)
     else:
         u = x.view(np.uint32).copy()
         r = rng.integers(0, 5, size=x.shape)

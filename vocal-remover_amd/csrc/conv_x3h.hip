@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256, (X3hCfg<MT, TH>::OCC + (HI ? 1 : 0))) void con
             if (((upm[PAR] >> cl) & 1u) && tid < Cfg::LSLOT) lq[cl * Cfg::LSLOT] = xr[PAR][0][cl];
     };
     // ---- the running power-of-two shift of the pixels (header): x' = x * 2^sh ----
-    int sh = 0;
+    int sh = 0, shlo = 0;                                          // (shlo: the shift the largest chunk so far asked for)
     float psc = 1.f;                                               // 2^sh
     // max |x| over this thread's pixel registers of set PAR -> wave maximum -> LDS (read back behind the next barrier)
     auto post_max = [&](auto par) {
@@ -340,9 +340,16 @@ __global__ __launch_bounds__(256, (X3hCfg<MT, TH>::OCC + (HI ? 1 : 0))) void con
     // the shift follows the chunk maxima (header): `e` = biased exponent of the largest |x| of the chunk about to be split
     auto follow = [&](int e, bool first) {
         const int need = 140 - (e < 14 ? 14 : e);                                  // chunk maximum -> [2^13, 2^14)
+        // The shift never runs more than 2^64 ahead of the LARGEST chunk seen so far (smallest `need`): that chunk's sums (<= 2^42 in
+        // its own scale) must survive every later multiplication of the accumulators -- chunks 2^64 below it do not matter anyway.
+        shlo = (first || need < shlo) ? need : shlo;
         int nsh = sh;
         if (first || need < sh - 1) nsh = need;                                    // (larger than 2^15 after scaling: must move)
-        else if (need > sh + 12) nsh = need < sh + 64 ? need : sh + 64;            // (maximum below 2: the second plane starts losing bits)
+        else if (need > sh + 12) {                                                 // (maximum below 2: the second plane starts losing bits)
+            nsh = need < sh + 64 ? need : sh + 64;
+            nsh = nsh < shlo + 64 ? nsh : shlo + 64;
+            nsh = nsh > sh ? nsh : sh;
+        }
         if (nsh != sh) {
             if (!first) {
                 const int d = nsh - sh;                                            // <= 64; a large negative d flushes the old sums

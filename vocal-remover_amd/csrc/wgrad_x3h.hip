@@ -255,10 +255,17 @@ __global__ __launch_bounds__(384, 3) void wgrad_x3h_kernel(const WgradArgs a) {
             for (int r = 0; r < 16; ++r) acc[t][nj][r] = 0.f;
 
     // the shifts follow the tile maxima (conv_x3h.hip): moved when a maximum would leave [2^1, 2^15) after scaling
-    auto follow1 = [&](int e, int sh, bool first) -> int {
+    // (lo: the shift the largest tile so far asked for -- the shift never runs more than 2^64 ahead of it, conv_x3h.hip)
+    int lox = 0, loz = 0;
+    auto follow1 = [&](int e, int sh, int& lo, bool first) -> int {
         const int need = 140 - (e < 14 ? 14 : e);
+        lo = (first || need < lo) ? need : lo;
         if (first || need < sh - 1) return need;
-        if (need > sh + 12) return need < sh + 64 ? need : sh + 64;
+        if (need > sh + 12) {
+            int n = need < sh + 64 ? need : sh + 64;
+            n = n < lo + 64 ? n : lo + 64;
+            return n > sh ? n : sh;
+        }
         return sh;
     };
     auto follow = [&](bool first) {
@@ -266,7 +273,7 @@ __global__ __launch_bounds__(384, 3) void wgrad_x3h_kernel(const WgradArgs a) {
         if (dbg & 8) { if (first) { shx = shz = 0; scx = scz = 1.f; } return; }
         const int ex = __builtin_amdgcn_readfirstlane(max(max(max(M[0], M[1]), max(M[2], M[3])), max(M[4], M[5]))) >> 23;
         const int ez = __builtin_amdgcn_readfirstlane(max(max(max(M[8], M[9]), max(M[10], M[11])), max(M[12], M[13]))) >> 23;
-        const int nx = follow1(ex, shx, first), nz = follow1(ez, shz, first);
+        const int nx = follow1(ex, shx, lox, first), nz = follow1(ez, shz, loz, first);
         if (nx != shx || nz != shz) {
             if (!first) {
                 const int dx = nx - shx, dz_ = nz - shz;                 // each <= 64; a large negative one flushes the old sums
