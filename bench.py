@@ -57,7 +57,7 @@ import __graft_entry__  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense bf16 matrix peak (never the 2:1-sparsity figure)
 HBM_PEAK_TBS = 8.0
-PROFILE_ROUND = 'r04'              # profiles/<round>_{infer,tta,train}_pmc.json: the PMC passes `traffic` is read from
+PROFILE_ROUND = 'r05'              # profiles/<round>_{infer,tta,train}_pmc.json: the PMC passes `traffic` is read from
 
 # kernel name -> (class label, matrix pipe or None).  Everything not listed is priced against HBM when the library noted algorithmic
 # bytes for it, and reported as 'other' (latency / launch bound: LSTM recurrence, finalize kernels, descriptor refreshes) when not.
@@ -254,13 +254,16 @@ def roofline_from_rows(rows, pmc_name, conv_totals):
     dom = next(c for c in out if c['bound'] is not None)
     cms, cfl, cn, cby = conv_totals
     traffic, src = None, None
-    path = os.path.join(ROOT, 'profiles', pmc_name)
-    if os.path.exists(path):        # rocprofv3 PMC passes of this same command (counters cannot be read in-process)
-        traffic = json.load(open(path)).get('bytes_per_launch')
-        src = 'profiles/' + pmc_name
+    # rocprofv3 PMC passes of this same command (counters cannot be read in-process): this round's file, else the newest earlier one
+    for cand in [pmc_name] + [pmc_name.replace(PROFILE_ROUND, 'r%02d' % n, 1) for n in range(int(PROFILE_ROUND[1:]) - 1, 0, -1)]:
+        path = os.path.join(ROOT, 'profiles', cand)
+        if os.path.exists(path):
+            traffic = json.load(open(path)).get('bytes_per_launch')
+            src = 'profiles/' + cand
+            break
     total_ms = sum(c['ms_per_step'] for c in out)
     return {'bound': dom['bound'], 'kernel': dom['class'], 'achieved': dom['achieved'], 'peak': dom['peak'], 'unit': dom['unit'],
-            'frac': dom['frac'], 'traffic': traffic,
+            'frac': dom['frac'], 'traffic': traffic, 'traffic_source': src,
             'frac_note': 'the dominant class (largest share of the serialised kernel time: %.2f of %.2f ms) against ITS OWN ceiling; every '
                          'class is in `classes`: frac = max(executed FLOPs / pipe peak, algorithmic bytes / 8 TB/s) / measured time'
                          % (dom['ms_per_step'], total_ms),
@@ -280,6 +283,93 @@ def roofline_from_rows(rows, pmc_name, conv_totals):
                                       'gradient, weight gradient); rounds 1-3 counted the forward launches only and divided by all launches',
             'launches_per_step': sum(c['launches'] for c in out), 'conv_launches_per_step': cn, 'kernel_ms_per_step': total_ms,
             'conv_kernel_ms_per_step': cms, 'algorithmic_gflop_per_step': cfl / 1e9}
+
+
+# ---- the stdout line: small enough for any tail buffer (round 4's 33 KB line overflowed the driver's 8 KB tail and went unparsed) ----
+LINE_LIMIT = 4000                  # bytes; tests/test_bench_multirank.py asserts the line stays below it
+DETAIL_PATH = os.path.join(ROOT, 'gpurun_out', 'bench_detail.json')
+
+
+def _r(x, digits=5):
+    """Floats to `digits` significant digits (the full-precision figures are in the detail file)."""
+    if isinstance(x, float):
+        return float('%.*g' % (digits, x))
+    if isinstance(x, (list, tuple)):
+        return [_r(v, digits) for v in x]
+    return x
+
+
+def _short_class(label):
+    return label.split(':')[0].split(' (')[0].split(',')[0][:44]
+
+
+def compact_roofline(r, nclasses=6):
+    """Scalars of a roofline object + at most `nclasses` one-line class rows [class, ms per step, bound, frac]."""
+    if r is None:
+        return None
+    o = {k: _r(r.get(k)) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_bytes_per_launch', 'frac_fp32_equivalent',
+                                   'kernel_ms_per_step', 'conv_kernel_ms_per_step', 'launches_per_step', 'conv_launches_per_step')}
+    o['kernel'] = _short_class(r['kernel'])
+    o['classes'] = [[_short_class(c['class']), _r(c['ms_per_step'], 4), c['bound'], _r(c['frac'], 3)] for c in r['classes'][:nclasses]]
+    return o
+
+
+def compact_line(out):
+    """The ONE stdout line: the contract's keys, `roofline` (scalars + <= 6 class rows), `cpu_baseline`, and the other configurations as
+    {value, ms_per_step, frac}.  Everything else (classes in full, per-kernel rows, notes) goes to gpurun_out/bench_detail.json."""
+    line = {k: out[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                                    'vs_baseline', 'dtype', 'data') if k in out}
+    line['dtype_note'] = 'fp32 storage/accumulate; 3x3 s1 convs multiply as 3 fp16 MFMA products of 2-way split operands (fp32-grade, see DESIGN.md)'
+    line['ms_per_step_per_rank'] = out.get('ms_per_step_per_rank')          # unrounded: ms_per_step is their MAX
+    line['allreduce_ms'] = _r(out.get('allreduce_ms'), 4)
+    line['config'] = {k: _r(v) for k, v in out['config'].items()}
+    line['roofline'] = compact_roofline(out.get('roofline'))
+    for key in ('tta', 'train', 'train_bf16'):
+        if key in out:
+            sub = out[key]
+            c = {'value': sub['value'], 'ms_per_step': sub['ms_per_step']}
+            if sub.get('roofline'):
+                rr = sub['roofline']
+                c.update({'frac': _r(rr['frac'], 3), 'kernel': _short_class(rr['kernel']), 'bound': rr['bound'],
+                          'kernel_ms_per_step': _r(rr['kernel_ms_per_step'], 4),
+                          'classes': [[_short_class(x['class']), _r(x['ms_per_step'], 4), x['bound'], _r(x['frac'], 3)] for x in rr['classes'][:4]]})
+            if sub.get('global_batch') is not None:
+                c['global_batch'] = sub['global_batch']
+            if 'allreduce_ms' in sub:
+                c['allreduce_ms'] = _r(sub['allreduce_ms'], 4)
+                c['ms_per_step_per_rank'] = sub.get('ms_per_step_per_rank')
+            if sub.get('cpu_baseline'):
+                c['cpu_baseline'] = {k: _r(v) for k, v in sub['cpu_baseline'].items() if k != 'sample'}
+            line[key] = c
+    for key in ('fp32_mfma', 'split_bf16'):
+        if key in out:
+            line[key] = {w: {'value': _r(out[key][w]['value']), 'ms_per_step': _r(out[key][w]['ms_per_step'])} for w in ('infer', 'train')}
+    if 'cpu_baseline' in out:
+        cb = dict(out['cpu_baseline'])
+        cb['sample'] = cb.get('sample', '')[:160]
+        line['cpu_baseline'] = {k: _r(v) for k, v in cb.items()}
+    line['detail'] = 'gpurun_out/bench_detail.json'
+    text = json.dumps(line, separators=(',', ':'))
+    # belt and braces: shed optional parts rather than ever print a line a tail buffer would cut
+    for drop in (('split_bf16',), ('fp32_mfma',), ('train_bf16',), ('tta', 'classes'), ('train', 'classes'), ('roofline', 'classes')):
+        if len(text) <= LINE_LIMIT:
+            break
+        tgt = line
+        for k in drop[:-1]:
+            tgt = tgt.get(k, {})
+        tgt.pop(drop[-1], None)
+        text = json.dumps(line, separators=(',', ':'))
+    assert len(text) <= LINE_LIMIT, len(text)
+    return text
+
+
+def write_detail(out):
+    try:
+        os.makedirs(os.path.dirname(DETAIL_PATH), exist_ok=True)
+        with open(DETAIL_PATH, 'w') as f:
+            json.dump(out, f, indent=1)
+    except OSError as e:                      # a read-only checkout must not cost the run its line
+        print('bench.py: could not write %s: %s' % (DETAIL_PATH, e), file=sys.stderr)
 
 
 # ---- runtimes: the real one (HIP library + RCCL) and a stub that keeps ONLY the multi-rank control flow -----------------------
@@ -480,9 +570,11 @@ def main():
     args = ap.parse_args()
     if args.tta:
         args.mode = 'tta'
-    if os.environ.get('VR_BENCH_WATCHDOG'):
+    # a hung communicator must end in a traceback, not in the driver's timeout: 600 s by default for N > 1 (VR_BENCH_WATCHDOG=0 turns it off)
+    watchdog = int(os.environ.get('VR_BENCH_WATCHDOG', '600' if (args.gpus > 1 or int(os.environ.get('WORLD_SIZE', '1')) > 1) else '0'))
+    if watchdog > 0:
         import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ['VR_BENCH_WATCHDOG']), exit=True)
+        faulthandler.dump_traceback_later(watchdog, exit=True)
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         self_launch(args)
@@ -564,7 +656,7 @@ def main():
         out = {
             'metric': metric, 'value': res['frames_per_sec'], 'unit': 'spectrogram-frames/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': res['ms_per_step'],
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': res.get('dtype', SPLIT_DTYPE),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'dtype_note': res.get('dtype', SPLIT_DTYPE),
             'ms_per_step_per_rank': res.get('ms_per_step_per_rank'), 'allreduce_ms': res.get('allreduce_ms'),
             'data': 'synthetic (seeded noise + sines; seeded random weights, no baseline.pth exists)',
             'config': {'workload': workload, 'n_fft': N_FFT, 'hop': HOP, 'cropsize': CROP,
@@ -644,8 +736,10 @@ def main():
             out['cpu_baseline'] = wl.cpu_baseline('infer' if primary_mode in ('infer', 'tta') else 'train')
             if args.mode == 'all':
                 out['train']['cpu_baseline'] = wl.cpu_baseline('train')
+        write_detail(out)
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + '\n').encode())
+        sys.stderr.flush()
+        os.write(json_fd, (compact_line(out) + '\n').encode())
     rt.finish()
 
 

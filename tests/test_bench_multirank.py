@@ -34,6 +34,13 @@ def _run(cmd):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, 'exactly one JSON line (rank 0 only), got %d:\n%s' % (len(lines), r.stdout[-2000:])
+    # round 4's line was 33 KB and the driver, which keeps the last 8,001 characters of stdout, could not parse it (BENCH_r04.parsed: null):
+    # the line must survive ANY tail buffer of that size, also with stderr merged in front of it
+    assert len(lines[0]) < 4096, len(lines[0])
+    tail = (r.stderr + r.stdout)[-8000:]
+    last = json.loads(tail.splitlines()[-1])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'config', 'roofline'):
+        assert key in last, key
     return json.loads(lines[0])
 
 
@@ -56,7 +63,11 @@ def _check(out, world, steps, warmup):
     else:
         assert tr['allreduce_ms'] is None and out['cpu_baseline']['kind'] == 'port'
     roof = out['roofline']
-    assert roof['classes'][0]['class'].startswith('conv_x3') and roof['bound'] == 'mfma' and roof['peak'] == 2500.0
+    assert roof['classes'][0][0].startswith('conv_x3') and roof['bound'] == 'mfma' and roof['peak'] == 2500.0
+    assert len(roof['classes']) <= 6 and all(len(row) == 4 for row in roof['classes'])      # [class, ms per step, bound, frac]
+    assert 'kernels' not in roof and out['detail'] == 'gpurun_out/bench_detail.json'
+    detail = json.load(open(os.path.join(ROOT, 'gpurun_out', 'bench_detail.json')))
+    assert detail['roofline']['kernels'] and detail['roofline']['classes'][0]['class'].startswith('conv_x3')
     assert abs(roof['frac'] - 6 * 1e11 / 2500e12 / 0.5e-3) < 1e-9             # stub rows: 1e11 FLOPs in 0.5 ms on the bf16 pipe
 
 
@@ -121,6 +132,27 @@ def test_every_conv_and_wgrad_kernel_of_the_library_has_a_matrix_pipe_class():
     # ... and nothing else is claimed by a matrix-pipe class
     wrong = [n for n in names if n not in mac and bench.classify('vr::' + n)[0] is not None]
     assert not wrong, wrong
+
+
+def test_compact_line_of_a_real_33kb_result_fits_the_tail():
+    """The full round-4 result (profiles/r04_bench_all_builder_run.json, 33 KB: three roofline objects with ~90 kernel rows each) through
+    compact_line(): the contract's keys survive, the line is < 4 KB, and the last 8000 characters of stdout parse."""
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, 'profiles', 'r04_bench_all_builder_run.json')))
+    assert len(json.dumps(full)) > 30000
+    text = bench.compact_line(full)
+    assert len(text) <= bench.LINE_LIMIT < 4096
+    line = json.loads((('x' * 20000) + '\n' + text + '\n')[-8000:].splitlines()[-1])
+    assert line['value'] == full['value'] and line['ms_per_step'] == full['ms_per_step'] and line['steps'] == full['steps']
+    assert line['metric'] == full['metric'] and line['config']['workload'] == full['config']['workload']
+    r = line['roofline']
+    for key in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_bytes_per_launch'):
+        assert key in r, key
+    assert abs(r['frac'] - full['roofline']['frac']) < 1e-4 and 1 <= len(r['classes']) <= 6
+    assert line['cpu_baseline']['kind'] == 'port' and line['cpu_baseline']['cores'] == full['cpu_baseline']['cores']
+    assert abs(line['train']['value'] - full['train']['value']) < 1e-9 and 'frac' in line['train'] and 'frac' in line['tta']
+    assert line['fp32_mfma']['infer']['ms_per_step'] > 0
 
 
 COMM_PROBE = r'''
