@@ -80,17 +80,7 @@ int vr_set_mode(vr_handle h, int training);
  *       the 1x1 weight-gradient GEMM round their operands to bf16 (RNE, in registers); accumulation, every stored tensor, the
  *       master weights and Adam stay fp32.   -1 = back to the handle's default (3, or VR_MFMA_MODE).
  * "mfma_bf16": 1 = "mfma_mode" 1; 0 = back to the handle's default mode.
- * "wgrad_x3h" (default 0, or VR_WGRAD_X3H; mfma_mode 3 only): 1 = the 3x3 stride-1 weight gradients in the direct form with three fp16
- *   products per product (wgrad_x3h.hip: both operands split inside the kernel) instead of Winograd F(3x3,2x2) on the fp32 matrix pipe;
- *   as exact (tests), measured no faster (108-128 against 110 direct-equivalent TFLOP/s) -- an experiment kept for the next round.
- * "params_dirty": the parameter arena was written from outside (vr_param_arena).
- * "hip_graph" (default 0, or VR_HIP_GRAPH): 1 = vr_separate_wave with device-resident input and outputs (and without
- *   --postprocess) captures its whole launch sequence -- STFT, every crop of both lanes and their streams, masked iSTFT x2 -- as a
- *   hipGraph on the second call with the same (length, flags, batchsize, cropsize) and replays it afterwards: one hipGraphLaunch
- *   instead of ~300 kernel launches.  Results are bit-equal either way (tests); measured 7-8 % slower than the eager enqueue on
- *   ROCm 7.0, hence opt-in.
- * "conv_x3p" (default 0, or VR_CONV_X3P): eval only -- 1 = the 3x3 stride-1 convolutions read activations stored as three bf16
- *   planes (csrc/conv_x3p.hip); measured on a par with the default path, kept as an option.              */
+ * "params_dirty": the parameter arena was written from outside (vr_param_arena).   */
 int vr_set_option(vr_handle h, const char* name, int value);
 
 /* CascadedNet.forward (mode 0) / predict_mask (mode 1) / predict (mode 2)   lib/nets.py:82-141

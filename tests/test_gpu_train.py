@@ -88,59 +88,6 @@ def test_conv_backward_kernels_vs_autograd(vr, small_train, case):
     assert ew < 2e-4, 'wgrad max-abs/scale = %.3e' % ew
 
 
-X3H_WGRAD = [
-    # N, Cin, H, W, Cout, kind
-    (2, 40, 24, 64, 64, 'plain'),
-    (2, 97, 13, 48, 32, 'plain'),            # odd H (half a tile row), partial 32-column tile, one live channel in the last block
-    (1, 33, 9, 72, 128, 'plain'),
-    (3, 16, 8, 32, 16, 'plain'),             # couts padded 16 -> 32
-    (1, 70, 30, 160, 96, 'plain'),
-    (2, 40, 24, 64, 64, 'tiny_dz'),          # dz at 2^-100, x at 2^+60: exact power-of-two scaling of both operands
-    (2, 40, 64, 64, 32, 'band_scales'),      # every pair of rows at its own power of two (2^-30 .. 2^+30), in x and in dz: the running
-]                                            # shifts of wgrad_x3h.hip move up and down tile by tile and the accumulators follow
-
-
-@pytest.mark.parametrize('case', X3H_WGRAD, ids=[str(c) for c in X3H_WGRAD])
-def test_wgrad_three_fp16_products_vs_fp64(vr, small_train, case):
-    """wgrad_x3h.hip (mfma_mode 3: the 3x3 stride-1 weight gradient in the direct form, both operands split into two scaled fp16 planes
-    inside the kernel, three products) against an fp64 reference, beside the Winograd fp32-MFMA kernel (mode 0) on the same data:
-    error at most 3x that kernel's + 2e-7 of the gradient's scale, and under 1e-5."""
-    N, Cin, H, W, Cout, kind = case
-    model = small_train[0]
-    rng = np.random.default_rng(N * 1000 + Cin + W)
-    x = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
-    dz = rng.standard_normal((N, Cout, H, W)).astype(np.float32)
-    w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9.0)).astype(np.float32)
-    if kind == 'tiny_dz':
-        x, dz = (x * np.float32(2.0 ** 60)).astype(np.float32), (dz * np.float32(2.0 ** -100)).astype(np.float32)
-    elif kind == 'band_scales':
-        x = (x * (2.0 ** rng.integers(-30, 31, size=(N, 1, H // 2, 1))).repeat(2, 2)).astype(np.float32)
-        dz = (dz * (2.0 ** rng.integers(-30, 31, size=(N, 1, H // 2, 1))).repeat(2, 2)).astype(np.float32)
-    xt = torch.from_numpy(x).double()
-    wt = torch.from_numpy(w).double().requires_grad_(True)
-    F.conv2d(xt, wt, None, 1, 1).backward(torch.from_numpy(dz).double())
-    want = wt.grad.numpy()
-    scale = float(np.abs(want).max())
-    nat = vr.native
-    errs = {}
-    for mode in (0, 3):
-        dx = np.empty(x.shape, np.float32)
-        dwt = np.empty(w.shape, np.float32)
-        try:
-            model.set_option('mfma_mode', mode)
-            model.set_option('wgrad_x3h', 1)                               # (an opt-in: default is the Winograd kernel in every mode)
-            nat.check(nat.lib().vr_debug_conv2d_backward(model._handle.h, nat.np_ptr(x), N, Cin, H, W, nat.np_ptr(w), Cout, 3, 1, 1, 1, 0, None,
-                                                         ctypes.c_float(1.0), nat.np_ptr(dz), nat.np_ptr(dx), nat.np_ptr(dwt)))
-        finally:
-            model.set_option('mfma_mode', -1)
-            model.set_option('wgrad_x3h', -1)
-        assert np.isfinite(dwt).all()
-        errs[mode] = float(np.abs(dwt.astype(np.float64) - want).max()) / scale
-    print('%s: weight gradient max error / scale -- fp32-MFMA Winograd %.3e, three fp16 products %.3e' % (case, errs[0], errs[3]))
-    assert errs[3] != errs[0], 'the option did not reach wgrad_x3h'
-    assert errs[3] <= 3.0 * errs[0] + 2e-7 and errs[3] < 1e-5
-
-
 def _rel(a, b):
     return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
 

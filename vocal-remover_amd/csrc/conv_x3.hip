@@ -498,15 +498,6 @@ bool x3_pick(const ConvArgs& a, const ConvShape& s, X3Tile* t) {
             u = &c;
         }
     }
-    // conv_x3b.hip (round-4 experiment, VR_CONV_X3B=1 / 3; default OFF: 2-23 % slower layer for layer): 8-wave tiles with register-cached
-    // pixel rows and a double-buffered pixel image -- 64 couts x 16 rows (bit 0), 32 couts x 32 rows (bit 1)
-    static const int x3b_on = getenv("VR_CONV_X3B") ? atoi(getenv("VR_CONV_X3B")) : 0;
-    t->b = 0;
-    if (x3b_on && a.bf16 != 3) {
-        const long long tw = (a.Wout + 31) / 32;
-        if ((x3b_on & 1) && a.CoutPad % 64 == 0 && (long long)a.N * ((a.Hout + 15) / 16) * tw * (a.CoutPad / 64) >= 256) { t->MT = 64; t->TH = 16; t->b = 1; return true; }
-        if ((x3b_on & 2) && (long long)a.N * ((a.Hout + 31) / 32) * tw * (a.CoutPad / 32) >= 256) { t->MT = 32; t->TH = 32; t->b = 1; return true; }
-    }
     int MT = (a.CoutPad % 64 == 0) ? 64 : 32;
     int TH = 8;
     static const int force_mt = getenv("VR_X3_MT") ? atoi(getenv("VR_X3_MT")) : 0;
@@ -533,7 +524,6 @@ void x3_fill_tiling(ConvArgs& a, const X3Tile& t) {
 
 void x3_launch_conv(const ConvArgs& a, const X3Tile& t, hipStream_t st) {
     if (a.bf16 == 3) { x3h_launch_conv(a, t, st); return; }          // mfma_mode 3: three fp16 products (conv_x3h.hip)
-    if (t.b) { x3b_launch_conv(a, t, st); return; }
     if (t.MT == 64) x3_launch<64, 8>(a, st);
     else if (t.TH == 16) x3_launch<32, 16>(a, st);
     else x3_launch<32, 8>(a, st);

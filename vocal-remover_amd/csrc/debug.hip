@@ -55,71 +55,7 @@ void Model::debug_kernel(const std::string& name, const int64_t* dims, int ndims
         VR_CHECK(ndims >= nd && nfp >= nf && nin >= ni && nout >= no, -2, "vr_debug_kernel(" + name + "): too few arguments");
     };
     hipStream_t st = stream;
-    if (name == "conv_planes") {
-        // conv_x3p.hip in isolation.  dims N, H, W, Cout, C0, C1, C2, up0 (source 0 arrives at [H/2][W/2] and goes through the
-        // bilinear x2), th (0 = the launcher's choice, 8 / 16 = forced tile rows); fparams slope, has_epi;
-        // inputs x0, x1|null, x2|null (fp32 NCHW each), w [Cout][C0+C1+C2][3][3] (OIHW), epi [Cout][2]|null, bias [Cout]|null;
-        // outputs out fp32 [N,Cout,H,W], out_planes = the plane output summed back to fp32 [N,Cout,H,W]
-        need(9, 2, 6, 2);
-        const int N = (int)dims[0], H = (int)dims[1], W = (int)dims[2], Cout = (int)dims[3];
-        const int Cs[3] = {(int)dims[4], (int)dims[5], (int)dims[6]};
-        const int up0 = (int)dims[7], th = (int)dims[8];
-        const int Cin = Cs[0] + Cs[1] + Cs[2], CoutPad = (Cout + 31) / 32 * 32, Gout = (Cout + 7) / 8;
-        X3pArgs a{};
-        std::vector<std::unique_ptr<DevBuf>> keep;
-        std::vector<std::pair<Tensor, std::pair<char*, bool>>> conv;
-        int nchunk = 0;
-        X3pWDesc wd{};
-        for (int i = 0; i < 3; ++i) {
-            if (Cs[i] == 0) continue;
-            const int G = (Cs[i] + 7) / 8;
-            const bool up = (i == 0 && up0);
-            const int h = up ? H / 2 : H, w = up ? W / 2 : W;
-            keep.emplace_back(new DevBuf(in[i], (size_t)N * Cs[i] * h * w));
-            Tensor t = dense(keep.back()->p, N, Cs[i], h, w);
-            keep.emplace_back(new DevBuf((size_t)N * G * 3 * H * W * 4));
-            char* pl = reinterpret_cast<char*>(keep.back()->p);
-            conv.push_back({t, {pl, up}});
-            a.src[a.nsrc] = X3pSrc{pl, (long long)G * 3 * H * W * 16, (long long)3 * H * W * 16, G};
-            wd.seg[a.nsrc] = Cs[i];
-            a.nsrc++; nchunk += G;
-        }
-        VR_HIP(hipDeviceSynchronize());                  // (null-stream memsets of the buffers above)
-        for (auto& c : conv) {
-            if (c.second.second) launch_upsample2x_planes(c.first, c.second.first, st);
-            else launch_to_planes(c.first, c.second.first, st);
-        }
-        // OIHW -> [Cin][9][CoutPad] (the library's conv layout), then the plane-order table
-        std::vector<float> wk((size_t)Cin * 9 * CoutPad, 0.f);
-        for (int co = 0; co < Cout; ++co)
-            for (int ci = 0; ci < Cin; ++ci)
-                for (int t = 0; t < 9; ++t) wk[((size_t)ci * 9 + t) * CoutPad + co] = in[3][((size_t)co * Cin + ci) * 9 + t];
-        DevBuf dw(wk.data(), wk.size());
-        DevBuf dtab(x3p_weights_bytes(nchunk, CoutPad) / 4);
-        wd.w = dw.p; wd.o = dtab.p; wd.nchunk = nchunk; wd.CoutPad = CoutPad;
-        X3pWDesc* ddesc = nullptr;
-        VR_HIP(hipMalloc(reinterpret_cast<void**>(&ddesc), sizeof(X3pWDesc)));
-        struct FreeD { void* p; ~FreeD() { hipFree(p); } } free_d{ddesc};
-        VR_HIP(hipMemcpy(ddesc, &wd, sizeof wd, hipMemcpyHostToDevice));
-        launch_x3p_weights(ddesc, 1, (long long)nchunk * 8 * 9 * CoutPad, st);
-        DevBuf depi(fp[1] != 0.f ? in[4] : nullptr, (size_t)Cout * 2), dbias(in[5], (size_t)Cout);
-        DevBuf dout((size_t)N * Cout * H * W), dpl((size_t)N * Gout * 3 * H * W * 4), dback((size_t)N * Cout * H * W);
-        a.nchunk = nchunk; a.w = dtab.p; a.Cout = Cout; a.CoutPad = CoutPad;
-        a.bias = in[5] ? dbias.p : nullptr;
-        a.epi = fp[1] != 0.f ? depi.p : nullptr;
-        a.slope = fp[1] != 0.f ? fp[0] : 1.f;            // the activation belongs to the BatchNorm epilogue (lib/layers.py:21-22)
-        a.out = dout.p; a.oH = W; a.oC = (long long)H * W; a.oN = a.oC * Cout;
-        a.opl = reinterpret_cast<char*>(dpl.p);
-        a.N = N; a.H = H; a.W = W;
-        VR_HIP(hipDeviceSynchronize());                  // the buffers' null-stream memsets must land before kernels on the handle's stream write them
-        if (th == 8 || th == 16) setenv("VR_X3P_TH_DEBUG", th == 8 ? "8" : "16", 1); else unsetenv("VR_X3P_TH_DEBUG");
-        x3p_launch(a, st);
-        unsetenv("VR_X3P_TH_DEBUG");
-        launch_planes_to_f32(reinterpret_cast<const char*>(dpl.p), dback.p, N, Cout, H, W, st);
-        VR_HIP(hipStreamSynchronize(st));
-        dout.download(out[0]);
-        dback.download(out[1]);
-    } else if (name == "bn_backward") {
+    if (name == "bn_backward") {
         need(4, 3, 7, 6);
         const int N = (int)dims[0], C = (int)dims[1], H = (int)dims[2], W = (int)dims[3];
         const size_t n = (size_t)N * C * H * W;

@@ -61,8 +61,7 @@ void launch_wino_weights_batched(const WinoWDesc* d_descs, int n, long long max_
 size_t wino_weights6_bytes(int Cin, int CoutPad);                                           // U as three bf16 planes (mfma_mode 2)
 void launch_wino_weights6(const float* w, void* u6, int Cin, int CoutPad, hipStream_t st);
 // conv_x3.hip: direct 3x3 stride-1 conv, fp32 products from six bf16 products (mfma_mode 2)
-struct X3Tile { int MT, TH; int b = 0; };          // b: conv_x3b.hip's 8-wave tiling
-void x3b_launch_conv(const ConvArgs& a, const X3Tile& t, hipStream_t st);
+struct X3Tile { int MT, TH; };
 struct X3WDesc { const float* w; void* o; int Cin, KK, CoutPad; };                            // one layer of a batched weight split
 bool x3_pick(const ConvArgs& a, const ConvShape& s, X3Tile* t);
 void x3_fill_tiling(ConvArgs& a, const X3Tile& t);
@@ -76,30 +75,6 @@ void x3h_launch_conv(const ConvArgs& a, const X3Tile& t, hipStream_t st);
 void launch_x3h_weights(const float* w, void* o, int Cin, int KK, int CoutPad, hipStream_t st);
 void launch_x3h_weights_batched(const X3WDesc* d_descs, int n, long long max_elems, int max_cout_pad, hipStream_t st);
 void launch_upsample2x(const Tensor& x, float* out, hipStream_t st);   // dense [N][C][2H][2W], activated
-// conv_x3p.hip: the same convolution over activations stored as bf16 planes (eval), LDS-DMA loader, fp32 and / or plane outputs
-struct X3pSrc { const char* p; long long sN, sG; int ngroups; };      // planes [N][ngroups][3][H][W] units; sN / sG in BYTES
-struct X3pArgs {
-    X3pSrc src[3];
-    int nsrc, nchunk;              // nchunk = sum of ngroups
-    const void* w;                 // [nchunk][9][3][CoutPad][8 ch] bf16 (x3p_weights_kernel: the padded channel order of the sources)
-    int Cout, CoutPad;
-    const float* bias;             // [Cout] or null
-    const float* epi;              // folded BatchNorm [Cout][2] (scale, shift) or null
-    float slope;                   // activation slope (1 = identity)
-    float* out;                    // fp32 destination [n*oN + c*oC + h*oH + w] or null
-    long long oN, oC, oH;
-    char* opl;                     // plane destination, dense [N][ceil(Cout/8)][3][H][W] units, or null
-    int N, H, W;
-    int tiles_w, tiles_h, npt, nct;
-};
-struct X3pWDesc { const float* w; void* o; int seg[3]; int nchunk, CoutPad; };   // one layer of a batched weight build
-bool x3p_enabled();
-void x3p_launch(const X3pArgs& a, hipStream_t st);
-size_t x3p_weights_bytes(int nchunk, int CoutPad);
-void launch_x3p_weights(const X3pWDesc* d_descs, int n, long long max_elems, hipStream_t st);
-void launch_to_planes(const Tensor& x, void* out, hipStream_t st);                 // plain fp32 view -> planes
-void launch_upsample2x_planes(const Tensor& x, void* out, hipStream_t st);         // bilinear x2 of a plain fp32 tensor -> planes
-void launch_planes_to_f32(const char* pl, float* out, int N, int C, int H, int W, hipStream_t st);   // p1 + p2 + p3 (tests)
 
 // ---- lstm.hip -----------------------------------------------------------------------------------
 // gx: [N][2*4H][T] input projections (+bias) for both directions; whh: [2][4H][H];

@@ -64,12 +64,6 @@ struct Conv {
     float* wino = nullptr;          // eval: Winograd-transformed weights [Cin][16][CoutPad] (3x3 stride-1 layers)
     void* wino6 = nullptr;          // mfma_mode 2: the same as three bf16 planes (conv_wino.hip: wino_weights6_kernel)
     void* x3w = nullptr;            // mfma_mode 2: the direct weights as three bf16 planes (conv_x3.hip: x3_weights_kernel)
-    // eval, mfma_mode 2 (conv_x3p.hip): the same for the PADDED channel order of the layer's sources (every source of the virtual
-    // concat occupies whole 8-channel groups); the segmentation is recorded by the planning dry run, the table is built after it
-    void* x3p = nullptr;
-    int x3p_seg[3] = {0, 0, 0};
-    int x3p_nchunk = 0;
-    bool x3p_built = false;
 };
 
 struct LSTMMod {
@@ -139,7 +133,7 @@ public:
     void separate_wave_api(const float* wave, bool on_dev, long long L, int tta, int batchsize, int cropsize,
                            float* y_wave, float* v_wave, bool out_on_dev);
     void separate_wave_body(const float* wave, bool on_dev, long long L, int tta, int batchsize, int cropsize,
-                            float* y_wave, float* v_wave, bool out_on_dev, bool staged_device_io);
+                            float* y_wave, float* v_wave, bool out_on_dev);
 
     // ---- debug / test hooks ----
     void debug_conv(const float* x, int N, int Cin, int H, int W, const float* w_oihw, int Cout, int KS, int stride,
@@ -175,26 +169,6 @@ public:
     void reset_adam_state();
     void profile_end(double* conv_ms, double* conv_flops, double* conv_bytes, int* launches);
 
-    // ---- hipGraph replay of the device-resident inference pipeline (separate_wave_api) ---------------------------------------
-    // One song = ~300 launches over 2 lanes x 2 streams in ~10 ms: enqueued from one host thread the second lane starts late and a
-    // serialised step shows ~10 us between kernels.  With input and outputs resident in HBM the whole call (STFT -> crops ->
-    // CascadedNet -> stitch -> masked iSTFT x2, all lanes and streams, their fork / join events) can be captured once per
-    // (length, flags, batch, crop) and replayed with one hipGraphLaunch; the wave is copied into / the stems out of fixed staging
-    // buffers around it.  Anything that may move a buffer or change the kernel choice bumps graph_epoch and drops the graph.
-    // OPT-IN (vr_set_option "hip_graph" / VR_HIP_GRAPH=1): on ROCm 7.0 the replay measured 7-8 % SLOWER than the eager enqueue, and a
-    // capture with forks inside both lanes crashes hipStreamEndCapture (the second lane therefore runs unforked inside the graph).
-    struct SepGraph { long long L = -1; int tta = 0, batchsize = 0, cropsize = 0; unsigned long long epoch = 0; int seen = 0;
-                      hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
-    SepGraph sep_graph;
-    float *sep_stage_y = nullptr, *sep_stage_v = nullptr;   // where separate_wave_body left the stems (staging buffers inside `io`)
-    unsigned long long graph_epoch = 1;
-    bool capturing = false;                              // inside hipStreamBeginCapture: no host synchronisation, no allocation
-    int graph_opt = -1;                                  // vr_set_option("hip_graph"): -1 default (VR_HIP_GRAPH, else OFF), 0 off, 1 on
-    bool graphs_on() const;
-    std::vector<hipEvent_t> cap_events; size_t cap_events_used = 0;
-    hipEvent_t ev(hipEvent_t regular);                   // capture: a fresh event per fork / join
-    void drop_sep_graph();
-    void sync_stream() { if (!capturing) VR_HIP(hipStreamSynchronize(stream)); }
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;          // eval mode: the high-band chain runs here
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -234,17 +208,6 @@ private:
     X3Batch xb_fwd, xb_bwd;
     void run_x3_batch(X3Batch& b, std::vector<X3WDesc>& descs);
     void refresh_wino(bool with_dgrad);
-    char* x3p_arena = nullptr;                           // eval: plane-order weight tables of the 3x3 stride-1 layers (conv_x3p.hip)
-    X3pWDesc* x3p_descs = nullptr; size_t x3p_descs_cap = 0;
-    void refresh_x3p();                                  // builds the tables whose segmentation is known and that are stale
-    // vr_set_option("conv_x3p"): -1 = the default (VR_CONV_X3P, else OFF: measured no faster than conv_x3.hip and its producers cost
-    // more than the split pass they replace -- DESIGN.md section 3), 0 off, 1 on
-    int x3p_opt = -1;
-    // vr_set_option("wgrad_x3h"): mfma_mode 3 only -- the 3x3 stride-1 weight gradients in the direct three-fp16-product form
-    // (wgrad_x3h.hip) instead of Winograd on the fp32 pipe.  Default OFF (VR_WGRAD_X3H=1 turns it on): correct and as exact, but no faster
-    int wgrad_x3h_opt = -1;
-    bool wgrad_x3h_on() const;
-    bool x3p_on() const { return !training && mfma_mode == 2 && (x3p_opt < 0 ? x3p_enabled() : x3p_opt != 0); }
     // batched refresh: descriptor tables (host copy + device copy, re-uploaded only when a pointer changed)
     struct WinoBatch { std::vector<WinoWDesc> host; WinoWDesc* dev = nullptr; long long max_elems = 0; };
     WinoBatch wb_fwd, wb_bwd, wb_fwd6, wb_bwd6;
@@ -352,10 +315,8 @@ public:
     void* wire_buf = nullptr;                            // bf16 copy of the gradient bucket (wire_dtype 1)
 private:
     void build_fwd_args(Conv& L, const std::vector<SrcSpec>& srcs, int N, bool batch_as_h, ConvArgs& a);
-    bool run_conv_x3p(Conv& L, const std::vector<SrcSpec>& srcs, int N, const Tensor* out_view, const float* bias, int fmt, Tensor* out);
-    // fmt (eval, conv_x3p.hip launches only): 0 = fp32 output, 2 = fp32 AND bf16 planes (tensors that feed 3x3 stride-1 convs)
     Tensor run_conv(Conv& L, const std::vector<SrcSpec>& srcs, int N, const Tensor* out_view, const float* bias,
-                    bool batch_as_h, int fmt = 0);
+                    bool batch_as_h);
     template <class F> void for_each_conv(F&& f);
     Tensor run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, const Tensor* out_view);
     Tensor run_lstm(LSTMMod& M, const Tensor& h);

@@ -235,8 +235,6 @@ void Model::finalize_layout() {
 }
 
 Model::~Model() {
-    drop_sep_graph();
-    for (hipEvent_t e : cap_events) hipEventDestroy(e);
     if (g_launch_prof == launch_prof) g_launch_prof = nullptr;
     prof_destroy(launch_prof);
     int prev_dev = -1;
@@ -334,48 +332,11 @@ void Model::fold_eval_affines() {
     for (BN* b : bn_list) maxC = std::max(maxC, std::max(b->C, b->bcast));
     launch_bn_fold_eval(d_fold, (int)bn_list.size(), maxC, 1e-5f, stream);
     refresh_wino(false);        // the weights may have changed too (set_param / Adam)
-    for (Conv* L : wino_list) L->x3p_built = false;
-    refresh_x3p();
     affine_dirty = false;
-}
-
-// Plane-order weight tables (conv_x3p.hip) of the layers whose source segmentation the planning dry run has recorded.
-void Model::refresh_x3p() {
-    if (!x3p_on()) return;
-    if (!x3p_arena) {
-        size_t total = 0;
-        for (Conv* L : wino_list) total += x3p_weights_bytes((L->Cin + 7) / 8 + 2, L->CoutPad);
-        VR_HIP(hipMalloc(reinterpret_cast<void**>(&x3p_arena), total ? total : 16));
-        size_t off = 0;
-        for (Conv* L : wino_list) { L->x3p = x3p_arena + off; off += x3p_weights_bytes((L->Cin + 7) / 8 + 2, L->CoutPad); }
-    }
-    std::vector<X3pWDesc> d;
-    long long max_elems = 0;
-    for (Conv* L : wino_list) {
-        if (L->x3p_nchunk == 0 || L->x3p_built) continue;
-        X3pWDesc e{};
-        e.w = L->w->dev; e.o = L->x3p; e.nchunk = L->x3p_nchunk; e.CoutPad = L->CoutPad;
-        for (int i = 0; i < 3; ++i) e.seg[i] = L->x3p_seg[i];
-        d.push_back(e);
-        max_elems = std::max(max_elems, (long long)L->x3p_nchunk * 8 * 9 * L->CoutPad);
-        L->x3p_built = true;
-    }
-    if (d.empty()) return;
-    if (d.size() > x3p_descs_cap) {
-        VR_HIP(hipStreamSynchronize(stream));
-        if (x3p_descs) VR_HIP(hipFree(x3p_descs));
-        x3p_descs_cap = wino_list.size();
-        VR_HIP(hipMalloc(reinterpret_cast<void**>(&x3p_descs), x3p_descs_cap * sizeof(X3pWDesc)));
-    }
-    VR_HIP(hipMemcpyAsync(x3p_descs, d.data(), d.size() * sizeof(X3pWDesc), hipMemcpyHostToDevice, stream));
-    VR_HIP(hipStreamSynchronize(stream));                 // (d is a local; rare: once per weight change)
-    launch_x3p_weights(x3p_descs, (int)d.size(), max_elems, stream);
 }
 
 void Model::set_option(const std::string& name, int value) {
     plan_peak = 0;                                           // kernel choice and scratch layout depend on the options: re-plan the next forward
-    ++graph_epoch;                                           // ... and a captured inference graph has them baked in
-    if (name == "hip_graph") { graph_opt = value < 0 ? -1 : (value != 0); return; }
     if (name == "train_winograd") train_wino = value != 0;
     else if (name == "serial_exec") serial = value != 0;     // every kernel on the handle's one stream (race detector of the tests)
     else if (name == "params_dirty") affine_dirty = true;    // the parameter arena was written from outside (vr_param_arena)
@@ -384,8 +345,6 @@ void Model::set_option(const std::string& name, int value) {
         if (value < -1 || value > 3) throw Error(-2, "mfma_mode: 0, 1, 2, 3 or -1 (default)");
         mfma_mode = value < 0 ? default_mfma_mode : value; affine_dirty = true;   // (the next eval forward refreshes the derived weight copies)
     }
-    else if (name == "wgrad_x3h") { wgrad_x3h_opt = value < 0 ? -1 : (value != 0); }
-    else if (name == "conv_x3p") { x3p_opt = value < 0 ? -1 : (value != 0); affine_dirty = true; }   // eval: 3x3 stride-1 convs over bf16-plane tensors (conv_x3p.hip)
     else if (name == "adam_reset") reset_adam_state();      // a freshly constructed torch.optim.Adam has no moments
     else throw Error(-2, "unknown option: " + name);
 }
@@ -485,11 +444,6 @@ void Model::refresh_wino(bool with_dgrad) {
     run_wino_batch(wb_bwd, d, false);
 }
 
-bool Model::wgrad_x3h_on() const {
-    static const bool env = [] { const char* e = getenv("VR_WGRAD_X3H"); return e && atoi(e) != 0; }();
-    return mfma_mode == 3 && (wgrad_x3h_opt < 0 ? env : wgrad_x3h_opt != 0);
-}
-
 void Model::run_x3_batch(X3Batch& b, std::vector<X3WDesc>& descs) {
     if (descs.empty()) return;
     bool same = b.dev && b.host.size() == descs.size();
@@ -537,34 +491,8 @@ void Model::run_wino_batch(WinoBatch& b, std::vector<WinoWDesc>& descs, bool spl
 // =====================================================================================================
 // workspace
 // =====================================================================================================
-bool Model::graphs_on() const {
-    // default OFF: measured SLOWER than the eager 2 lanes x 2 streams enqueue (S30 song: 11.66 vs 10.84 ms, --tta 23.85 vs 22.05 ms)
-    static const bool env_on = [] { const char* e = getenv("VR_HIP_GRAPH"); return e && atoi(e) != 0; }();
-    return graph_opt < 0 ? env_on : graph_opt != 0;
-}
-
-// While capturing, every fork / join gets its own event: re-recording one event object several times inside a capture crashed
-// hipStreamEndCapture (ROCm 7.0: segmentation fault with the 2 lanes x 2 streams of one song; a single stream captures fine).
-hipEvent_t Model::ev(hipEvent_t regular) {
-    if (!capturing) return regular;
-    if (cap_events_used == cap_events.size()) {
-        hipEvent_t e = nullptr;
-        VR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        cap_events.push_back(e);
-    }
-    return cap_events[cap_events_used++];
-}
-
-void Model::drop_sep_graph() {
-    if (sep_graph.exec) hipGraphExecDestroy(sep_graph.exec);
-    if (sep_graph.graph) hipGraphDestroy(sep_graph.graph);
-    sep_graph = SepGraph{};
-}
-
 void Model::ensure_ws(size_t bytes) {
     if (bytes <= ws.cap) return;
-    VR_CHECK(!capturing, -3, "workspace growth during graph capture");
-    ++graph_epoch;
     VR_HIP(hipStreamSynchronize(stream));
     if (ws.base) VR_HIP(hipFree(ws.base));
     ws.base = nullptr; ws.cap = 0;
@@ -586,8 +514,6 @@ void Model::swap_lane(int i) {
 
 void Model::ensure_io(size_t bytes) {
     if (bytes <= io.cap) return;
-    VR_CHECK(!capturing, -3, "staging growth during graph capture");
-    ++graph_epoch;
     VR_HIP(hipStreamSynchronize(stream));
     if (io.base) VR_HIP(hipFree(io.base));
     io.base = nullptr; io.cap = 0;
@@ -758,87 +684,8 @@ void Model::build_fwd_args(Conv& L, const std::vector<SrcSpec>& srcs, int N, boo
     a.pad_h = L.pad_h; a.pad_w = L.pad_w;
 }
 
-// Eval, mfma_mode 2: a 3x3 stride-1 launch over bf16-plane sources (conv_x3p.hip).  Sources that do not carry planes yet are
-// converted (to_planes_kernel: thin tensors -- the network input, stage outputs, the LSTM branch, stride-2 conv outputs).
-bool Model::run_conv_x3p(Conv& L, const std::vector<SrcSpec>& srcs, int N, const Tensor* out_view, const float* bias, int fmt, Tensor* out) {
-    if (!x3p_on() || !(L.KS == 3 && L.stride == 1 && L.dh == 1 && L.dw == 1 && L.pad_h == 1 && L.pad_w == 1)) return false;
-    if (srcs.empty() || srcs.size() > 3) return false;
-    int H = -1, W = -1, ctot = 0;
-    for (const SrcSpec& sp : srcs) {
-        const Tensor& t = sp.t;
-        if (sp.up || sp.bcastH || t.aff0 || t.aff1 || t.post || t.slope != 1.f) return false;     // plain tensors only (eval)
-        if (H < 0) { H = t.H; W = t.W; }
-        VR_CHECK(t.H == H && t.W == W, -5, "h1_shape[3] must be greater than h2_shape[3] (decoder skip/upsample size mismatch in " + L.name + ")");
-        ctot += t.C;
-    }
-    if (W < 32) return false;
-    VR_CHECK(ctot == L.Cin, -2, "conv " + L.name + ": channel count mismatch");
-    bool found = false;
-    for (Conv* q : wino_list) found = found || q == &L;
-    if (!found) return false;
-    X3pArgs a{};
-    a.nsrc = (int)srcs.size();
-    int seg[3] = {0, 0, 0}, nchunk = 0;
-    for (int i = 0; i < a.nsrc; ++i) {
-        const Tensor& t = srcs[i].t;
-        const int G = (t.C + 7) / 8;
-        const size_t bytes = (size_t)t.N * G * 3 * H * W * 16;
-        const char* pl = t.pl;
-        if (!pl) {
-            VR_CHECK(t.p != nullptr, -2, "conv " + L.name + ": source without values");
-            char* buf = static_cast<char*>(ws.alloc(bytes));
-            if (!dry) launch_to_planes(t, buf, stream);
-            pl = buf;
-        }
-        a.src[i] = X3pSrc{pl, (long long)G * 3 * H * W * 16, (long long)3 * H * W * 16, G};
-        seg[i] = t.C; nchunk += G;
-    }
-    if (L.x3p_nchunk != nchunk || L.x3p_seg[0] != seg[0] || L.x3p_seg[1] != seg[1] || L.x3p_seg[2] != seg[2]) {
-        VR_CHECK(dry, -2, "conv " + L.name + ": plane-order weight table does not match the sources (no planning pass ran)");
-        L.x3p_nchunk = nchunk; L.x3p_seg[0] = seg[0]; L.x3p_seg[1] = seg[1]; L.x3p_seg[2] = seg[2];
-        L.x3p_built = false;
-    }
-    a.nchunk = nchunk;
-    a.w = L.x3p; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
-    a.bias = bias;
-    a.epi = L.bn ? L.bn->affine : nullptr;
-    a.slope = L.bn ? L.slope : 1.f;
-    a.N = N; a.H = H; a.W = W;
-    Tensor o;
-    o.N = N; o.C = L.Cout; o.H = H; o.W = W; o.slope = 1.f;
-    if (out_view) {
-        VR_CHECK(out_view->H == H && out_view->W == W && out_view->C == L.Cout, -2, "conv " + L.name + ": output view shape mismatch");
-        o.p = out_view->p; o.sN = out_view->sN; o.sC = out_view->sC; o.sH = out_view->sH;
-    } else {
-        o.p = ws.allocf((size_t)N * L.Cout * H * W);
-        o.sH = W; o.sC = (long long)H * W; o.sN = o.sC * L.Cout;
-    }
-    a.out = o.p; a.oN = o.sN; a.oC = o.sC; a.oH = o.sH;
-    if (fmt == 2) {
-        char* pl = static_cast<char*>(ws.alloc((size_t)N * ((L.Cout + 7) / 8) * 3 * H * W * 16));
-        a.opl = pl; o.pl = pl;
-    }
-    if (!dry) {
-        VR_CHECK(L.x3p_built && L.x3p != nullptr, -2, "conv " + L.name + ": plane-order weight table not built");
-        record_begin(0, 2.0 * N * (double)H * W * (double)L.Cout * L.Cin * 9);
-        if (profiling) {
-            char tag[160];
-            snprintf(tag, sizeof tag, "%s k3 s1 d1 ci%d co%d %dx%dx%d (planes)", L.name.c_str(), L.Cin, L.Cout, N, H, W);
-            record_note(4.0 * ((double)N * L.Cin * H * W + (double)N * L.Cout * H * W + (double)L.Cin * 9 * L.Cout), tag);
-        }
-        x3p_launch(a, stream);
-        record_end();
-    }
-    *out = o;
-    return true;
-}
-
 Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs_in, int N, const Tensor* out_view, const float* bias,
-                       bool batch_as_h, int fmt) {
-    if (!training && !batch_as_h) {
-        Tensor o;
-        if (run_conv_x3p(L, srcs_in, N, out_view, bias, fmt, &o)) return o;
-    }
+                       bool batch_as_h) {
     // Training: give the conv plain inputs (one element-wise / upsample pass per source) -- the forward conv
     // then takes the LDS-DMA kernel and the weight gradient re-reads the same buffers without arithmetic.
     std::vector<SrcSpec> srcs = srcs_in;
@@ -1035,19 +882,6 @@ Model::SrcSpec Model::upsampled(const Tensor& t) {
     // layers read the LOW-resolution tensor (a quarter of the bytes) and nothing is materialised.  Measured per layer (tools/
     // x3_proto.hip): it pays from 512 x 128 output pixels on (dec1, stage-3 dec2); below, the interpolation VALU of the many-channel
     // layers costs more than the HBM-bound upsample pass.
-    // Plane path (conv_x3p.hip): the x2 result is written as bf16 planes by an HBM-bound pass -- its interpolation and split VALU
-    // cost nothing there, and the consuming conv pulls it by LDS-DMA.  Every decoder conv is 3x3 stride-1: it takes the plane kernel
-    // from 32 output columns on.
-    if (x3p_on() && 2 * t.W >= 32 && !t.aff0 && !t.aff1 && !t.post && t.slope == 1.f && t.p) {
-        Tensor u;
-        u.N = t.N; u.C = t.C; u.H = 2 * t.H; u.W = 2 * t.W;
-        u.sH = u.W; u.sC = (long long)u.H * u.W; u.sN = u.sC * u.C; u.slope = 1.f;
-        u.p = nullptr;
-        char* buf = static_cast<char*>(ws.alloc((size_t)u.N * ((u.C + 7) / 8) * 3 * u.H * u.W * 16));
-        if (!dry) launch_upsample2x_planes(t, buf, stream);
-        u.pl = buf;
-        return SrcSpec{u};
-    }
     static const bool fuse_on = !(getenv("VR_X3_FUSE_UP") && atoi(getenv("VR_X3_FUSE_UP")) == 0);
     static const bool x3_on = !(getenv("VR_CONV_X3") && atoi(getenv("VR_CONV_X3")) == 0);
     if (fuse_on && x3_on && x3_mode() && 4LL * t.H * t.W >= 65536 && 2 * t.W >= 32 && !t.aff0 && !t.aff1 && !t.post && t.slope == 1.f) {
@@ -1067,13 +901,11 @@ Model::SrcSpec Model::upsampled(const Tensor& t) {
 Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, const Tensor* out_view) {
     const std::string& p = B.prefix;
     Tensor e[5];
-    // e1..e4 feed a stride-2 conv (fp32) AND, as skip connections, a decoder conv (planes on the plane path)
-    const int skip_fmt = x3p_on() ? 2 : 0;
-    e[0] = run_conv(B.enc1, in, N, nullptr, nullptr, false, skip_fmt);
+    e[0] = run_conv(B.enc1, in, N, nullptr, nullptr, false);
     tap(p + ".e1", e[0]);
     for (int i = 0; i < 4; ++i) {
         Tensor t = run_conv(B.enc_a[i], {SrcSpec{e[i]}}, N, nullptr, nullptr, false);
-        e[i + 1] = run_conv(B.enc_b[i], {SrcSpec{t}}, N, nullptr, nullptr, false, i < 3 ? skip_fmt : 0);
+        e[i + 1] = run_conv(B.enc_b[i], {SrcSpec{t}}, N, nullptr, nullptr, false);
         tap(p + ".e" + std::to_string(i + 2), e[i + 1]);
     }
     // layers.ASPPModule.forward (lib/layers.py:92-105)
@@ -1105,7 +937,7 @@ Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, co
     const bool afk = aspp_fork && !serial && !training && !dry && !profiling && side_stream != nullptr && !band_fork_active;
     hipStream_t aspp_main = stream;
     if (afk) {
-        hipEvent_t ef = ev(ev_fork);
+        hipEvent_t ef = ev_fork;
         VR_HIP(hipEventRecord(ef, aspp_main));
         VR_HIP(hipStreamWaitEvent(side_stream, ef, 0));
     }
@@ -1119,7 +951,7 @@ Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, co
     }
     if (afk) {
         stream = aspp_main;
-        hipEvent_t ej = ev(ev_join);
+        hipEvent_t ej = ev_join;
         VR_HIP(hipEventRecord(ej, side_stream));
         VR_HIP(hipStreamWaitEvent(aspp_main, ej, 0));
     }
@@ -1146,12 +978,12 @@ Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, co
     hipEvent_t lstm_join = nullptr;
     if (fk) {
         hipStream_t ms = stream;
-        hipEvent_t ef = ev(ev_fork);
+        hipEvent_t ef = ev_fork;
         VR_HIP(hipEventRecord(ef, ms));
         VR_HIP(hipStreamWaitEvent(side_stream, ef, 0));
         stream = side_stream;
         try { uh = upsampled(h); } catch (...) { stream = ms; throw; }
-        lstm_join = ev(ev_join);
+        lstm_join = ev_join;
         VR_HIP(hipEventRecord(lstm_join, side_stream));
         stream = ms;
     }
@@ -1196,7 +1028,7 @@ Tensor Model::run_net(const Tensor& x) {
     const bool fork = band_fork && !serial && !dry && (!training || train_fork) && !profiling && side_stream != nullptr;
     hipStream_t main_stream = stream;
     if (fork) {
-        hipEvent_t ef = ev(ev_fork);
+        hipEvent_t ef = ev_fork;
         VR_HIP(hipEventRecord(ef, main_stream));
         VR_HIP(hipStreamWaitEvent(side_stream, ef, 0));
         band_fork_active = true;                 // until the join: the side stream belongs to the high-band chain
@@ -1215,7 +1047,7 @@ Tensor Model::run_net(const Tensor& x) {
     Tensor h2 = run_basenet(nets_[3], {SrcSpec{xh}, SrcSpec{h1}}, B, &v);
     for (size_t i = tape_hi0; i < tape.size(); ++i) tape[i].chain = 1;    // backward may run these beside the low chain
     if (fork) {
-        hipEvent_t ej = ev(ev_join);
+        hipEvent_t ej = ev_join;
         VR_HIP(hipEventRecord(ej, side_stream));
         stream = main_stream;
         VR_HIP(hipStreamWaitEvent(main_stream, ej, 0));
@@ -1251,7 +1083,6 @@ void Model::plan_and_reserve(int B, int T, size_t extra_bytes) {
     ws = saved;
     ensure_ws(need);
     ws.reset();
-    refresh_x3p();                               // (segmentations the dry run has just recorded)
 }
 
 static void check_T(int T, int offset, int mode) {
@@ -1549,8 +1380,6 @@ void Model::separate_api(const float* spec, bool on_dev, int T, int tta, int bat
             // crops [i, i+nb) in K contiguous parts; part 0 on the handle's own streams, part j on lane j-1
             for (Lane& l : lanes) {
                 if (l.ws.cap >= ws.cap) continue;            // every lane plans for the same (bs, cropsize)
-                VR_CHECK(!capturing, -3, "lane workspace growth during graph capture");
-                ++graph_epoch;
                 VR_HIP(hipDeviceSynchronize());
                 if (l.ws.base) VR_HIP(hipFree(l.ws.base));
                 l.ws.base = nullptr; l.ws.cap = 0;
@@ -1559,7 +1388,7 @@ void Model::separate_api(const float* spec, bool on_dev, int T, int tta, int bat
             }
             const int per = (nb + K - 1) / K;
             for (int j = 1; j < K; ++j) {                    // `mag` is ready at this point of the main stream
-                hipEvent_t es = ev(lanes[j - 1].start);
+                hipEvent_t es = lanes[j - 1].start;
                 VR_HIP(hipEventRecord(es, stream));
                 VR_HIP(hipStreamWaitEvent(lanes[j - 1].main, es, 0));
             }
@@ -1568,13 +1397,8 @@ void Model::separate_api(const float* spec, bool on_dev, int T, int tta, int bat
                 const int first = j * per, count = std::min(per, nb - first);
                 if (count <= 0) break;
                 swap_lane(j - 1);
-                // (capture: the second lane keeps its two band chains on one stream -- with forks inside BOTH lanes hipStreamEndCapture
-                // crashes on ROCm 7.0, whichever of the band / ASPP / LSTM forks it is; each lane alone, or lanes without inner forks, capture fine)
-                hipStream_t side_saved = side_stream;
-                if (capturing) side_stream = nullptr;
-                try { run_crops(i + first, count); } catch (...) { side_stream = side_saved; swap_lane(j - 1); throw; }
-                side_stream = side_saved;
-                hipEvent_t done = ev(lanes[j - 1].done);
+                try { run_crops(i + first, count); } catch (...) { swap_lane(j - 1); throw; }
+                hipEvent_t done = lanes[j - 1].done;
                 VR_HIP(hipEventRecord(done, stream));
                 swap_lane(j - 1);
                 VR_HIP(hipStreamWaitEvent(stream, done, 0));
@@ -1603,7 +1427,7 @@ void Model::separate_api(const float* spec, bool on_dev, int T, int tta, int bat
         for (int which = 0; which < 2; ++which)
             launch_istft_masked(plan, reinterpret_cast<const float2*>(sd), hop, T, mask[0], Wm[0], tta ? mask[1] : nullptr, Wm[1],
                                 roi / 2, wgt, which, which ? v_wave_d : y_wave_d, stream);
-        sync_stream();
+        VR_HIP(hipStreamSynchronize(stream));
         return;
     }
     launch_apply_mask(reinterpret_cast<const float2*>(sd), bins, T, mask[0], Wm[0], tta ? mask[1] : nullptr, Wm[1], roi / 2,
@@ -1619,106 +1443,22 @@ void Model::separate_wave_api(const float* wave, bool on_dev, long long L, int t
                               float* y_wave, float* v_wave, bool out_on_dev) {
     DeviceGuard dev_guard(device);
     VR_CHECK(L >= hop, -2, "wave shorter than one hop");
-    const bool graphable = on_dev && out_on_dev && !(tta & 2) && graphs_on() && !profiling && !serial && !record_taps && !training &&
-                           istft_masked_available(plan, hop) && L / hop >= 1;
-    if (!graphable) {
-        separate_wave_body(wave, on_dev, L, tta, batchsize, cropsize, y_wave, v_wave, out_on_dev, false);
-        return;
-    }
-    fold_eval_affines();                                 // (may launch table refreshes and synchronise: outside the graph)
-    SepGraph& g = sep_graph;
-    const bool same = g.L == L && g.tta == tta && g.batchsize == batchsize && g.cropsize == cropsize && g.epoch == graph_epoch;
-    if (!same) {
-        drop_sep_graph();
-        g.L = L; g.tta = tta; g.batchsize = batchsize; g.cropsize = cropsize; g.epoch = graph_epoch; g.seen = 0;
-    }
-    const size_t in_bytes = (size_t)2 * L * sizeof(float);
-    const size_t out_bytes = (size_t)2 * hop * (size_t)(L / hop) * sizeof(float);
-    if (!g.exec && g.seen >= 1) {
-        // second call with this shape: everything is allocated, planned and attribute-set -- capture it
-        hipGraph_t graph = nullptr;
-        static const bool gdbg = getenv("VR_GRAPH_DEBUG") != nullptr;
-        if (gdbg) fprintf(stderr, "[graph] begin capture\n");
-        cap_events_used = 0;
-        VR_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-        capturing = true;
-        // every other stream joins the capture as a DIRECT child of the origin stream first (and is joined back at the end): with
-        // lane 1's side stream entering only through lane 1's main stream -- a fork of a fork -- hipStreamEndCapture crashed (ROCm 7.0)
-        std::vector<hipStream_t> others;
-        if (side_stream) others.push_back(side_stream);
-        for (Lane& l : lanes) { if (l.main) others.push_back(l.main); if (l.side) others.push_back(l.side); }
-        {
-            hipEvent_t root = ev(nullptr);
-            VR_HIP(hipEventRecord(root, stream));
-            for (hipStream_t o : others) VR_HIP(hipStreamWaitEvent(o, root, 0));
-        }
-        static const bool gser = getenv("VR_GRAPH_SERIAL") != nullptr;
-        const bool serial_saved = serial;
-        if (gser) serial = true;
-        try {
-            separate_wave_body(nullptr, true, L, tta, batchsize, cropsize, nullptr, nullptr, true, true);
-            serial = serial_saved;
-            for (hipStream_t o : others) {
-                hipEvent_t j = ev(nullptr);
-                VR_HIP(hipEventRecord(j, o));
-                VR_HIP(hipStreamWaitEvent(stream, j, 0));
-            }
-        } catch (...) {
-            capturing = false;
-            serial = serial_saved;
-            hipStreamEndCapture(stream, &graph);
-            if (graph) hipGraphDestroy(graph);
-            throw;
-        }
-        capturing = false;
-        if (gdbg) fprintf(stderr, "[graph] body enqueued\n");
-        VR_HIP(hipStreamEndCapture(stream, &graph));
-        if (gdbg) fprintf(stderr, "[graph] capture ended\n");
-        hipGraphExec_t exec = nullptr;
-        const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        if (gdbg) fprintf(stderr, "[graph] instantiate rc %d\n", (int)e);
-        if (e != hipSuccess || g.epoch != graph_epoch) {          // (an epoch bump during capture cannot happen: growth throws)
-            if (exec) hipGraphExecDestroy(exec);
-            hipGraphDestroy(graph);
-            (void)hipGetLastError();
-            g.seen = -1000000;                                     // do not try again for this shape
-        } else {
-            g.graph = graph; g.exec = exec;
-        }
-    }
-    if (g.exec) {
-        // the staging layout of separate_wave_body(staged_device_io): wave at the start of `io`, the stems behind the spectrogram buffers
-        float* win = reinterpret_cast<float*>(io.base);
-        VR_HIP(hipMemcpyAsync(win, wave, in_bytes, hipMemcpyDeviceToDevice, stream));
-        VR_HIP(hipGraphLaunch(g.exec, stream));
-        { static const bool gd = getenv("VR_GRAPH_DEBUG") != nullptr; if (gd) fprintf(stderr, "[graph] launched\n"); }
-        VR_HIP(hipMemcpyAsync(y_wave, sep_stage_y, out_bytes, hipMemcpyDeviceToDevice, stream));
-        VR_HIP(hipMemcpyAsync(v_wave, sep_stage_v, out_bytes, hipMemcpyDeviceToDevice, stream));
-        VR_HIP(hipStreamSynchronize(stream));
-        return;
-    }
-    separate_wave_body(wave, true, L, tta, batchsize, cropsize, y_wave, v_wave, true, false);
-    if (g.seen >= 0) g.seen += 1;
+    separate_wave_body(wave, on_dev, L, tta, batchsize, cropsize, y_wave, v_wave, out_on_dev);
 }
 
-// staged_device_io (graph capture): the input wave is expected at a fixed staging buffer (start of `io`) and the stems are left in
-// fixed staging buffers (sep_stage_y / sep_stage_v) -- the caller copies around the graph launch; no host copies, no synchronisation.
 void Model::separate_wave_body(const float* wave, bool on_dev, long long L, int tta, int batchsize, int cropsize,
-                               float* y_wave, float* v_wave, bool out_on_dev, bool staged_device_io) {
+                               float* y_wave, float* v_wave, bool out_on_dev) {
     const int T = 1 + (int)(L / hop);
     const int bins = output_bin;
     const size_t spec_f = (size_t)2 * bins * T * 2;
     const size_t out_f = (size_t)2 * hop * (T - 1);
     const size_t frames_f = (size_t)2 * T * n_fft;
     const size_t scratch = separate_scratch_floats(bins, T, cropsize, offset, tta);
-    // (the staging buffers of the graph path are always part of the layout, so that eager warm-up calls and the captured call agree)
     ensure_io(((size_t)2 * L + 3 * spec_f + 2 * out_f + frames_f + scratch) * sizeof(float) + 65536);
     io.reset();
     float* stage_in = io.allocf((size_t)2 * L);
     const float* wd = wave;
-    if (staged_device_io) {
-        wd = stage_in;
-    } else if (!on_dev) {
+    if (!on_dev) {
         VR_HIP(hipMemcpyAsync(stage_in, wave, (size_t)2 * L * sizeof(float), hipMemcpyHostToDevice, stream));
         wd = stage_in;
     }
@@ -1728,9 +1468,8 @@ void Model::separate_wave_body(const float* wave, bool on_dev, long long L, int 
     float* frames = io.allocf(frames_f);
     float* stage_y = io.allocf(out_f + 4);
     float* stage_v = io.allocf(out_f + 4);
-    sep_stage_y = stage_y; sep_stage_v = stage_v;
-    float* yw = (out_on_dev && !staged_device_io) ? y_wave : stage_y;
-    float* vw = (out_on_dev && !staged_device_io) ? v_wave : stage_v;
+    float* yw = out_on_dev ? y_wave : stage_y;
+    float* vw = out_on_dev ? v_wave : stage_v;
     launch_stft(plan, wd, L, hop, T, reinterpret_cast<float2*>(spec), stream);
     if (istft_masked_available(plan, hop) && out_f) {
         separate_api(spec, true, T, tta, batchsize, cropsize, ys, vs, true, /*io_reserved=*/true, yw, vw);
@@ -1743,7 +1482,7 @@ void Model::separate_wave_body(const float* wave, bool on_dev, long long L, int 
         VR_HIP(hipMemcpyAsync(y_wave, yw, out_f * sizeof(float), hipMemcpyDeviceToHost, stream));
         VR_HIP(hipMemcpyAsync(v_wave, vw, out_f * sizeof(float), hipMemcpyDeviceToHost, stream));
     }
-    sync_stream();
+    VR_HIP(hipStreamSynchronize(stream));
 }
 
 // =====================================================================================================

@@ -168,7 +168,6 @@ void Model::bwd_conv(TapeRec& r) {
         else { w.zN = out.sN; w.zC = out.sC; w.zH = out.sH; }
         w.Cout = L.Cout; w.CoutPad = L.CoutPad;
         w.allow_wino = train_wino ? 1 : 0;
-        w.x3h = wgrad_x3h_on() ? 1 : 0;
         w.bf16 = mfma_mode;                      // 1: bf16 MFMA operands (wgrad_wino / wgrad_gemm); 2: split-bf16 products (wgrad_x3.hip)
         w.part = ws.allocf(wgrad_scratch_floats(w, shp));
         if (!dry) {

@@ -110,8 +110,6 @@ struct Tensor {
     float slope = 1.f;
     const float* post = nullptr;   // [N][C] post-activation multiplier (Dropout2d), or null
     float* g = nullptr;            // training: gradient w.r.t. the value consumers see (same strides as p)
-    const char* pl = nullptr;      // eval, mfma_mode 2: the same values as three bf16 planes, dense [N][ceil(C/8)][3][H][W] of 16-byte
-                                   // units (8 channels of one pixel in one plane; conv_x3p.hip) -- what the 3x3 stride-1 convs read
 };
 
 // One input of a (virtually concatenated) convolution.
@@ -185,7 +183,6 @@ struct WgradArgs {
     int dma;                   // 1: every source is a plain tensor -> the loader waves use LDS-DMA (no arithmetic)
     int bf16;                  // 1: bf16 MFMA operands (wgrad_wino.hip, wgrad_gemm.hip)
     int allow_wino;            // 1: 3x3 stride-1 layers with plain inputs may take the Winograd F(3x3,2x2) kernel (wgrad_wino.hip)
-    int x3h;                   // 1 (with bf16 == 3): ... or the direct three-fp16-product kernel (wgrad_x3h.hip; option "wgrad_x3h", default off)
 };
 double launch_wgrad(const WgradArgs& a, const ConvShape& s, float* grad_out, int accumulate, hipStream_t st);
 size_t wgrad_scratch_floats(const WgradArgs& a, const ConvShape& s);

@@ -438,9 +438,6 @@ bool wgrad_wino_pick(const WgradArgs& a, const ConvShape& s, int* CB_out, int* M
 void wgrad_wino_plan(WgradArgs& a, int CB, int MT);
 void wgrad_wino_launch(const WgradArgs& a, int CB, int MT, hipStream_t st);
 bool wgrad_gemm_pick(const WgradArgs& a, const ConvShape& s);                                   // wgrad_gemm.hip
-bool wgrad_x3h_pick(const WgradArgs& a, const ConvShape& s, int* MT_out);                       // wgrad_x3h.hip (mfma_mode 3)
-void wgrad_x3h_plan(WgradArgs& a, int MT);
-void wgrad_x3h_launch(const WgradArgs& a, int MT, hipStream_t st);
 void wgrad_gemm_plan(WgradArgs& a);
 void wgrad_gemm_launch(const WgradArgs& a, hipStream_t st);
 
@@ -506,17 +503,6 @@ static void wgrad_reduce(const WgradArgs& a, float* grad_out, int accumulate, hi
 double launch_wgrad(const WgradArgs& a_in, const ConvShape& s, float* grad_out, int accumulate, hipStream_t st) {
     WgradArgs a = a_in;
     VR_CHECK(a.part != nullptr, -2, "wgrad needs a scratch slab");
-    {
-        int MT = 0;
-        static const int xdbg = [] { const char* e = getenv("VR_WXH_DBG"); return e ? atoi(e) : 0; }();   // ablations (perf only)
-        a.in.dbg = xdbg;
-        if (wgrad_x3h_pick(a, s, &MT)) {                   // mfma_mode 3: direct form, three fp16 products per product
-            wgrad_x3h_plan(a, MT);
-            wgrad_x3h_launch(a, MT, st);
-            wgrad_reduce(a, grad_out, accumulate, st);
-            return 2.0 * a.in.N * (double)a.in.Hout * a.in.Wout * (double)a.Cout * a.in.Cin * 9;
-        }
-    }
     {
         int CB = 0, MT = 0;
         if (wgrad_wino_pick(a, s, &CB, &MT)) {             // Winograd F(3x3,2x2): 2.25x fewer MFMAs
@@ -590,12 +576,6 @@ size_t wgrad_scratch_floats(const WgradArgs& a_in, const ConvShape& s) {
             WgradArgs b = a_in;
             if (b.CoutPad % ((alt == 0 || alt == 3) ? 64 : 32)) continue;
             wgrad_wino_plan(b, (alt == 1 || alt == 3) ? 64 : 32, (alt == 0 || alt == 3) ? 64 : 32);
-            const size_t n = (size_t)b.P * (size_t)b.part_stride;
-            if (n > need) need = n;
-        }
-        {
-            WgradArgs b = a_in;
-            wgrad_x3h_plan(b, 32);
             const size_t n = (size_t)b.P * (size_t)b.part_stride;
             if (n > need) need = n;
         }
