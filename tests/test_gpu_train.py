@@ -394,3 +394,52 @@ def test_bf16_mfma_mode_single_convs(vr, small_train):
             assert 1e-6 < ew < 2e-2, (ks, ew)
     finally:
         model.set_option('mfma_bf16', 0)
+
+
+POISON_PROBE = r'''
+import sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import __graft_entry__
+from oracle import train_step, weights
+vr = __graft_entry__.load_package()
+n_fft, nout, nl, B, T = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
+sd = weights.make_state_dict(11, n_fft=n_fft, nout=nout, nout_lstm=nl)
+model = vr.nets.CascadedNet(n_fft, n_fft // 2, nout, nl)
+model.load_state_dict(sd)
+model.to(torch.device('cuda:0'))
+X, y = train_step.synth_batch(B, T=T, n_fft=n_fft, seed=5)
+masks = train_step.dropout_masks(B, seed=9, nout=nout)
+out = {}
+for step in range(2):                           # the second step runs over the first one's (poisoned again) arena
+    model.train(); model.set_dropout_masks(masks); model.zero_grad()
+    out['loss%d' % step] = np.float64(model.train_step(X.to('cuda:0'), y.to('cuda:0'), 1))
+    for k, v in model.grads().items():
+        out['g%d/%s' % (step, k)] = v.cpu().numpy()
+np.savez(sys.argv[2], **out)
+'''
+
+
+@pytest.mark.parametrize('cfg', [(512, 8, 32, 4, 128), (2048, 32, 128, 2, 256)], ids=['small', 'full'])
+def test_first_writer_stores_survives_a_poisoned_gradient_arena(tmp_path, cfg):
+    """First-writer-stores (train.hip / model.hip g_fresh): the activation-gradient arena is no longer zero-filled, a plain conv output's
+    gradient is STORED by its first backward writer.  Under VR_GS_POISON=1 the library fills the whole arena with NaN bit patterns
+    before every step (outside the ranges that are zero-filled on purpose): a writer that accumulates into a buffer nobody stored to --
+    an offset / partial view that misses g_fresh, a first writer that does not cover its tensor -- now yields NaNs.  Two steps in a
+    poisoned process must give finite gradients bit-equal to an unpoisoned process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for poison in ('0', '1'):
+        path = str(tmp_path / ('grads_%s.npz' % poison))
+        env = dict(os.environ, VR_GS_POISON=poison)
+        r = subprocess.run([sys.executable, '-c', POISON_PROBE, root, path] + [str(c) for c in cfg], capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        res[poison] = np.load(path)
+    a, b = res['0'], res['1']
+    assert set(a.files) == set(b.files) and len(a.files) > 100
+    for k in a.files:
+        assert np.isfinite(b[k]).all(), 'NaN / inf under VR_GS_POISON in %s' % k
+        assert np.array_equal(a[k], b[k]), 'VR_GS_POISON changes %s: some backward writer accumulates into an unwritten buffer' % k

@@ -1,6 +1,7 @@
 // Host-side model: parameter registry (reference state_dict keys), network topology of
 // lib/nets.py / lib/layers.py, forward executor, and the device-resident Separator pipeline.
 #pragma once
+#include <chrono>
 #include <deque>
 #include <map>
 #include <memory>
@@ -169,6 +170,7 @@ public:
     void reset_adam_state();
     void profile_end(double* conv_ms, double* conv_flops, double* conv_bytes, int* launches);
 
+    std::chrono::steady_clock::time_point enq_t1; bool enq_have = false;   // VR_ENQ_TIMING diagnostics (model.hip: separate_wave_body)
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;          // eval mode: the high-band chain runs here
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;

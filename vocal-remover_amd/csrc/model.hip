@@ -3,6 +3,7 @@
 #include "model.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -235,8 +236,8 @@ void Model::finalize_layout() {
 }
 
 Model::~Model() {
-    if (g_launch_prof == launch_prof) g_launch_prof = nullptr;
-    prof_destroy(launch_prof);
+    if (launch_prof && !prof_owned_by_this_thread(launch_prof)) prof_abandon(launch_prof);   // the opening thread still holds the pointer
+    else { if (g_launch_prof == launch_prof) g_launch_prof = nullptr; prof_destroy(launch_prof); }
     int prev_dev = -1;
     if (hipGetDevice(&prev_dev) != hipSuccess) prev_dev = -1;
     hipSetDevice(device);
@@ -545,6 +546,7 @@ void Model::record_end() {
 }
 
 void Model::profile_begin() {
+    VR_CHECK(!launch_prof || prof_owned_by_this_thread(launch_prof), -3, "vr_profile_begin: a profile opened by another thread is still open");
     prof_destroy(launch_prof);
     launch_prof = prof_create();
     g_launch_prof = launch_prof;
@@ -553,6 +555,7 @@ void Model::profile_begin() {
 
 void Model::profile_end(double* conv_ms, double* conv_flops, double* conv_bytes, int* launches) {
     DeviceGuard dev_guard(device);
+    VR_CHECK(!launch_prof || prof_owned_by_this_thread(launch_prof), -3, "vr_profile_end must be called from the thread that called vr_profile_begin");
     VR_HIP(hipDeviceSynchronize());                      // every stream the profiled step used
     g_launch_prof = nullptr;
     profiling = false;
@@ -579,6 +582,12 @@ bool Model::g_first(const float* g) {
 
 // zero the buffers of `gs` that need it (ranges recorded by the planning dry run; adjacent ones merged)
 void Model::clear_gs_zero_ranges(hipStream_t st) {
+    // VR_GS_POISON=1 (debug): every byte of the arena is first set to 0xFF (a NaN pattern), so a backward writer that ACCUMULATES into a
+    // buffer nobody stored to first (first-writer-stores keys g_fresh by the exact base pointer: an offset or partial view would get
+    // g_first() == false) turns its tensor into NaNs instead of silently adding to last step's values -- the train-parity tests run
+    // once under it (tests/test_gpu_train.py)
+    static const bool poison = [] { const char* e = getenv("VR_GS_POISON"); return e && atoi(e) != 0; }();
+    if (poison && gs.base && gs.cap) VR_HIP(hipMemsetAsync(gs.base, 0xFF, gs.cap, st));
     size_t i = 0;
     while (i < gs_zero_plan.size()) {
         size_t b = gs_zero_plan[i].first, e = b + gs_zero_plan[i].second;
@@ -1427,6 +1436,7 @@ void Model::separate_api(const float* spec, bool on_dev, int T, int tta, int bat
         for (int which = 0; which < 2; ++which)
             launch_istft_masked(plan, reinterpret_cast<const float2*>(sd), hop, T, mask[0], Wm[0], tta ? mask[1] : nullptr, Wm[1],
                                 roi / 2, wgt, which, which ? v_wave_d : y_wave_d, stream);
+        enq_t1 = std::chrono::steady_clock::now(); enq_have = true;       // (VR_ENQ_TIMING: everything is enqueued at this point)
         VR_HIP(hipStreamSynchronize(stream));
         return;
     }
@@ -1448,6 +1458,19 @@ void Model::separate_wave_api(const float* wave, bool on_dev, long long L, int t
 
 void Model::separate_wave_body(const float* wave, bool on_dev, long long L, int tta, int batchsize, int cropsize,
                                float* y_wave, float* v_wave, bool out_on_dev) {
+    // VR_ENQ_TIMING=1 (diagnostics): host time to ENQUEUE the whole call vs the time until the device has drained it
+    static const bool enq_timing = getenv("VR_ENQ_TIMING") != nullptr;
+    const auto enq_t0 = std::chrono::steady_clock::now();
+    struct EnqReport {
+        Model* m; bool on; std::chrono::steady_clock::time_point t0;
+        ~EnqReport() {
+            if (!on || !m->enq_have) return;
+            const auto t2 = std::chrono::steady_clock::now();
+            fprintf(stderr, "[vr-enq] enqueue %.3f ms, total %.3f ms\n", std::chrono::duration<double, std::milli>(m->enq_t1 - t0).count(),
+                    std::chrono::duration<double, std::milli>(t2 - t0).count());
+            m->enq_have = false;
+        }
+    } enq_report{this, enq_timing, enq_t0};
     const int T = 1 + (int)(L / hop);
     const int bins = output_bin;
     const size_t spec_f = (size_t)2 * bins * T * 2;

@@ -3,11 +3,13 @@
 // Measurement infrastructure for bench.py's `roofline.classes` -- nothing here runs unless vr_profile_begin was called.
 #include <cxxabi.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "vr_common.h"
@@ -24,6 +26,10 @@ struct LaunchRec {
 };
 
 struct LaunchProfiler {
+    // g_launch_prof is thread-local: only the thread that opened the profile can clear its own pointer.  A handle closed from ANOTHER
+    // thread marks the profiler dead and leaks it (a few KB) instead of freeing memory the opening thread's VR_LAUNCH would still touch.
+    std::thread::id owner = std::this_thread::get_id();
+    std::atomic<bool> dead{false};
     std::vector<LaunchRec> recs;
     bool pend = false, pend_strong = false;
     double pend_flops = 0, pend_bytes = 0;
@@ -53,6 +59,7 @@ void prof_note_clear() {
 
 void prof_before(const void* fn, const char* label, hipStream_t st) {
     LaunchProfiler* p = g_launch_prof;
+    if (p->dead.load(std::memory_order_acquire)) { g_launch_prof = nullptr; return; }     // its handle was closed from another thread
     LaunchRec r;
     r.fn = fn; r.label = label;
     if (p->pend) { r.flops = p->pend_flops; r.bytes = p->pend_bytes; r.noted = true; r.tag = p->pend_tag; p->pend = false; }
@@ -63,8 +70,13 @@ void prof_before(const void* fn, const char* label, hipStream_t st) {
 }
 
 void prof_after(hipStream_t st) {
-    VR_HIP(hipEventRecord(g_launch_prof->recs.back().e1, st));
+    LaunchProfiler* p = g_launch_prof;
+    if (!p || p->recs.empty()) return;
+    VR_HIP(hipEventRecord(p->recs.back().e1, st));
 }
+
+bool prof_owned_by_this_thread(const LaunchProfiler* p) { return p && p->owner == std::this_thread::get_id(); }
+void prof_abandon(LaunchProfiler* p) { if (p) p->dead.store(true, std::memory_order_release); }
 
 void prof_memset_async(void* ptr, int value, size_t bytes, hipStream_t st) {
     if (g_launch_prof) {

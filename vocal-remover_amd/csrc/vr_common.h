@@ -70,6 +70,8 @@ void prof_note_update(double bytes, const char* tag);           // add bytes / t
 void prof_note_clear();
 LaunchProfiler* prof_create();
 void prof_destroy(LaunchProfiler* p);
+bool prof_owned_by_this_thread(const LaunchProfiler* p);      // g_launch_prof is thread-local: begin / end / close belong to one thread
+void prof_abandon(LaunchProfiler* p);                         // closed from another thread: mark dead (leaked on purpose), never freed under a live VR_LAUNCH
 void prof_collect(LaunchProfiler* p, double* conv_ms, double* conv_flops, double* conv_bytes, int* conv_launches, std::string* report,
                   bool dump);
 void prof_before(const void* fn, const char* label, hipStream_t st);
