@@ -95,9 +95,22 @@ struct X3hCfg {
     static_assert(TH % 4 == 0 && MT % 32 == 0 && LDS_BYTES <= 80 * 1024 && 2 * NXL + NWMIN < 64 && NXL <= 30 && LSLOT <= 256, "tile");
 };
 
+// ---- phase trace (diagnostics, VR_CONV_DBG bit 64): four workgroups in the middle of the grid stamp s_memtime at the phase boundaries
+// of chunks 2..7, wave by wave -- where a chunk's ~14 k cycles go (multiply phase / pixel wait / barriers / split pass / weight wait).
+// Layout [workgroup 4][wave 4][chunk 6][point 8]; read back with vr_debug_trace (api.cpp), tools/x3h_trace.py prints it.
+__device__ long long g_x3h_trace[4 * 4 * 6 * 8];
+void x3h_trace_read(long long* host, int n) {
+    VR_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_x3h_trace), sizeof(long long) * (size_t)(n < 768 ? n : 768)));
+}
+void x3h_trace_clear() {
+    static long long zeros[768] = {0};
+    VR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_x3h_trace), zeros, sizeof zeros));
+}
+
 // UP: some source arrives through the fused bilinear x2 (eval); the plain instantiation sheds that path's registers and code
+// TRACE: the diagnostic build of the same kernel (phase stamps; never launched unless VR_CONV_DBG has bit 64)
 // HI: one more workgroup per CU than the register budget of the UP form allows (plain form only: 153 / 113 registers)
-template <int MT, int TH, bool UP, bool HI>
+template <int MT, int TH, bool UP, bool HI, bool TRACE = false>
 __global__ __launch_bounds__(256, (X3hCfg<MT, TH>::OCC + (HI ? 1 : 0))) void conv_x3h_kernel(const ConvArgs a) {
     using Cfg = X3hCfg<MT, TH>;
     constexpr int TW = Cfg::TW, KK = Cfg::KK, PW = Cfg::PW, NSLOT = Cfg::NSLOT, NPASS = Cfg::NPASS, WM = Cfg::WM, WN = Cfg::WN,
@@ -128,6 +141,14 @@ __global__ __launch_bounds__(256, (X3hCfg<MT, TH>::OCC + (HI ? 1 : 0))) void con
     const int nchunk = (a.Cin + 7) >> 3;
     const unsigned lds0 = (unsigned)(size_t)smem_x3h;
     const int dbg = a.dbg & 15;
+    const bool prio = (a.dbg & 32) != 0;                          // experiment: s_setprio 1 over the matrix instructions of a chunk
+    const int trace_wg = TRACE ? (int)blockIdx.x - (int)(gridDim.x / 2) : -1;
+    auto stamp = [&](int k, int point) {
+        if (TRACE && trace_wg >= 0 && trace_wg < 4 && k >= 2 && k < 8) {
+            const long long t = __builtin_readcyclecounter();
+            if (lane == 0) g_x3h_trace[((trace_wg * 4 + wave) * 6 + (k - 2)) * 8 + point] = t;
+        }
+    };
 
     // ---- this thread's pixels of the halo tile: byte offset in a channel plane = row * (4 * sH) + 4 * column (2^31: padding);
     // recomputed from the thread index whenever the source (= the row pitch) changes, instead of held in registers ----
@@ -393,6 +414,7 @@ __global__ __launch_bounds__(256, (X3hCfg<MT, TH>::OCC + (HI ? 1 : 0))) void con
     auto chunk = [&](int k, auto par) {
         constexpr int PAR = decltype(par)::value;                 // k & 1: the pixel registers chunk k came from (free again)
         const bool more = k + 1 < nchunk;
+        stamp(k, 0);
         {
             const char* Wb = smem_x3h + Cfg::P_BYTES + PAR * Cfg::W_BYTES;
             vr_f16x8 A[2][WM], B[2][WN];
@@ -430,6 +452,7 @@ __global__ __launch_bounds__(256, (X3hCfg<MT, TH>::OCC + (HI ? 1 : 0))) void con
                     for (int ni = 0; ni < WN; ++ni) acc[mi][ni] = mfma_f16x16(A[buf][mi], B[buf][ni], acc[mi][ni]);
             };
             read_group(0, 0);
+            if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int g = 0; g < Cfg::NG; ++g) {
                 const int cur = g & 1;
@@ -444,19 +467,27 @@ __global__ __launch_bounds__(256, (X3hCfg<MT, TH>::OCC + (HI ? 1 : 0))) void con
                 mfma_group(cur);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (prio) __builtin_amdgcn_s_setprio(0);
         }
+        stamp(k, 1);
         if (more) {
             using Q = std::integral_constant<int, PAR ^ 1>;
             // outstanding, oldest first: chunk k+1's pixels | weights of chunk k+1 | chunk k+2's pixels
             wait_pixels(Q{}, std::integral_constant<int, Cfg::NXL + Cfg::NWMIN>{});
+            stamp(k, 2);
             post_max(Q{});
             if (any_up) stage_lowres(Q{});
+            stamp(k, 3);
             lds_barrier();                                       // every wave has read P(k); maxima and the low-resolution tile of chunk k+1 are in LDS
+            stamp(k, 4);
             follow(read_max_exp(), false);
             if (dbg != 3) convert(Q{});
+            stamp(k, 5);
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(Cfg::NXL) : "memory");   // weights of chunk k+1 landed
+            stamp(k, 6);
             __builtin_amdgcn_s_barrier();                        // P(k+1) complete
             asm volatile("" ::: "memory");
+            stamp(k, 7);
         }
     };
     for (int k = 0; k < nchunk; k += 2) {
@@ -604,10 +635,10 @@ void launch_x3h_weights_batched(const X3WDesc* d_descs, int n, long long max_ele
     VR_HIP(hipGetLastError());
 }
 
-template <int MT, int TH, bool UP, bool HI>
+template <int MT, int TH, bool UP, bool HI, bool TRACE = false>
 static void x3h_launch_up(const ConvArgs& a, hipStream_t st) {
     using Cfg = X3hCfg<MT, TH>;
-    auto kern = conv_x3h_kernel<MT, TH, UP, HI>;
+    auto kern = conv_x3h_kernel<MT, TH, UP, HI, TRACE>;
     static std::atomic<unsigned long long> attr_done{0};
     ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
     const int groups = (a.npt + 7) / 8;
@@ -618,6 +649,11 @@ static void x3h_launch_up(const ConvArgs& a, hipStream_t st) {
 template <int MT, int TH>
 static void x3h_launch(const ConvArgs& a, hipStream_t st) {
     static const int hi = [] { const char* e = getenv("VR_X3H_HI"); return e ? atoi(e) : 0; }();
+    if (a.dbg & 64) {                                             // diagnostic build with phase stamps (tools/x3h_trace.py)
+        if (a.src[0].up | a.src[1].up | a.src[2].up) x3h_launch_up<MT, TH, true, false, true>(a, st);
+        else x3h_launch_up<MT, TH, false, false, true>(a, st);
+        return;
+    }
     if (a.src[0].up | a.src[1].up | a.src[2].up) x3h_launch_up<MT, TH, true, false>(a, st);
     else if (hi && TH == 8) x3h_launch_up<MT, TH, false, (TH == 8)>(a, st);
     else x3h_launch_up<MT, TH, false, false>(a, st);

@@ -55,6 +55,19 @@ void Model::debug_kernel(const std::string& name, const int64_t* dims, int ndims
         VR_CHECK(ndims >= nd && nfp >= nf && nin >= ni && nout >= no, -2, "vr_debug_kernel(" + name + "): too few arguments");
     };
     hipStream_t st = stream;
+    if (name == "x3h_trace") {
+        // conv_x3h.hip phase stamps (VR_CONV_DBG bit 64).  dims[0]: 0 = clear, 1 = read into out[0] (768 floats: cycles relative to the
+        // earliest stamp, -1 where nothing was stamped); layout [workgroup 4][wave 4][chunk 6][point 8]
+        need(1, 0, 0, dims[0] ? 1 : 0);
+        VR_HIP(hipDeviceSynchronize());
+        if (!dims[0]) { x3h_trace_clear(); return; }
+        long long raw[768];
+        x3h_trace_read(raw, 768);
+        long long lo = 0;
+        for (long long v : raw) if (v && (!lo || v < lo)) lo = v;
+        for (int i = 0; i < 768; ++i) out[0][i] = raw[i] ? (float)(raw[i] - lo) : -1.f;
+        return;
+    }
     if (name == "bn_backward") {
         need(4, 3, 7, 6);
         const int N = (int)dims[0], C = (int)dims[1], H = (int)dims[2], W = (int)dims[3];

@@ -72,6 +72,8 @@ void launch_x3_weights_batched(const X3WDesc* d_descs, int n, long long max_elem
 // conv_x3h.hip: the same convs with fp32-grade products from three fp16 products (mfma_mode 3); weights in the SAME buffers
 // (x3_weights_bytes), format [chunk][tap][2][CoutPad][8] fp16 + per-cout scale tails
 void x3h_launch_conv(const ConvArgs& a, const X3Tile& t, hipStream_t st);
+void x3h_trace_read(long long* host, int n);          // diagnostics: phase stamps of the TRACE build (VR_CONV_DBG bit 64)
+void x3h_trace_clear();
 void launch_x3h_weights(const float* w, void* o, int Cin, int KK, int CoutPad, hipStream_t st);
 void launch_x3h_weights_batched(const X3WDesc* d_descs, int n, long long max_elems, int max_cout_pad, hipStream_t st);
 void launch_upsample2x(const Tensor& x, float* out, hipStream_t st);   // dense [N][C][2H][2W], activated
