@@ -600,7 +600,10 @@ __global__ __launch_bounds__(256, 3) void conv_dma_s2d_kernel(const ConvArgs a) 
 // Fused stride-2 data gradient: dz is a single plain source, weights = the four class arrays of launch_s2_class_weights.
 bool s2d_fused_eligible(const ConvArgs& a) {
     static const int enabled = getenv("VR_S2D_FUSED") ? atoi(getenv("VR_S2D_FUSED")) : 1;
-    if (!enabled || a.nsrc != 1 || (a.Cin & 3) || a.Wout < 32 || (a.Win & 3)) return false;
+    // (16-wide dz, the 1/16-resolution encoders: half of each 32-column tile is padding -- zero-filled by the loader's range check and
+    // skipped by the stores -- and the launch still runs ~2x faster than the zero-insertion fallback of conv_ws.hip: 16-23 TFLOP/s)
+    static const int min_w = getenv("VR_S2D_MIN_W") ? atoi(getenv("VR_S2D_MIN_W")) : 16;
+    if (!enabled || a.nsrc != 1 || (a.Cin & 3) || a.Wout < min_w || (a.Win & 3)) return false;
     const ConvSrc& c = a.src[0];
     if (!src_plain(c) || c.W != a.Win) return false;
     if ((long long)c.H * (c.sH > 0 ? c.sH : 1) * 4 >= 0x7FFFFFF0LL) return false;

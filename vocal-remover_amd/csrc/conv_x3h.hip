@@ -41,6 +41,13 @@ __device__ __forceinline__ float x3h_load(i32x4 rsrc, int voff) {
     asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(rsrc) : "memory");
     return v;
 }
+// the same with a scalar byte offset on top (not part of the descriptor's range check on gfx9: a padding pixel, vector offset 2^31,
+// still reads 0) -- one descriptor and one vector offset serve the eight channels of a chunk
+__device__ __forceinline__ float x3h_load_s(i32x4 rsrc, int voff, unsigned soff) {
+    float v;
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    return v;
+}
 // s_waitcnt vmcnt(N) that the uses of the eight registers cannot be scheduled across
 template <int N>
 __device__ __forceinline__ void x3h_wait8(float (&r)[8]) {
@@ -78,7 +85,10 @@ struct X3hCfg {
     static constexpr int NWP = KK * 2 * MT;                      // 16-byte weight operands per chunk
     static constexpr int W_BYTES = NWP * 16;
     static constexpr int NWPASS = (NWP + 255) / 256;
-    // fused bilinear x2 (lib/layers.py:52): the low-resolution pixels under the halo tile, [8 ch][LROWS][LW] fp32
+    // fused bilinear x2 (lib/layers.py:52): the low-resolution pixels under the halo tile, [LROWS][LW][8 ch] fp32 -- channel innermost, so
+    // that a staging thread stores its 8 channels as two 16-byte writes and an interpolating thread fetches the 8 channels of a
+    // neighbour as two ds_read_b128 (round 5: the [8 ch][LROWS][LW] form cost 32 four-byte reads per pixel, issued channel by channel
+    // behind scalar branches with the LDS latency exposed each time -- 3.9 k of the 13.5 k cycles of a chunk, profiles/r05_x3h_phase_trace.txt)
     static constexpr int LROWS = TH / 2 + 3, LW = 20, LSLOT = LROWS * LW;
     static constexpr int L_OFF = P_BYTES + 2 * W_BYTES;
     static constexpr int L_BYTES = CK * LSLOT * 4;
@@ -181,7 +191,7 @@ __global__ __launch_bounds__(256, (X3hCfg<MT, TH>::OCC + (HI ? 1 : 0))) void con
             const bool ok = s < NSLOT && hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win;
             const float h1r = us.rh * (float)(ok ? hi : 0), w1r = us.rw * (float)(ok ? wi : 0);
             const int h1 = (int)h1r, w1 = (int)w1r;
-            lidx[p] = ok ? ((h1 - lr0) * Cfg::LW + (w1 - lc0)) * 4 : -1;
+            lidx[p] = ok ? ((h1 - lr0) * Cfg::LW + (w1 - lc0)) * 32 : -1;        // byte offset of the pixel's 8 channels in the staging tile
             lh[p] = h1r - (float)h1;
             lw_[p] = w1r - (float)w1;
         }
@@ -231,8 +241,28 @@ __global__ __launch_bounds__(256, (X3hCfg<MT, TH>::OCC + (HI ? 1 : 0))) void con
     // Every chunk issues the SAME number of loads (channels beyond Cin read through an empty descriptor), so the hand-placed
     // s_waitcnt counts are compile-time constants.
     float xr[2][NPASS][8];
+    // Round 5: a chunk whose eight channels are all live, all in the CURRENT source and not upsampled -- nearly every chunk -- takes a
+    // short path: one descriptor on the chunk's first channel plane, channel cl at scalar offset cl * (channel stride); the general
+    // path below costs ~30 scalar instructions and several branches per channel (the ISA of the chunk loop had 660 scalar instructions
+    // beside 56 matrix instructions).  Same number of loads in the same order either way: the hand-placed waits do not change.
+    bool fastc[2] = {false, false};
     auto load_channel = [&](int k, int cl, auto par) {
         constexpr int PAR = decltype(par)::value;
+        if (cl == 0) {
+            const int c0 = k * 8;
+            if (c0 < a.Cin && dbg != 1 && c0 >= xend) next_source();
+            if (c0 < a.Cin && dbg != 1 && c0 >= xend) next_source();
+            fastc[PAR] = c0 + 8 <= a.Cin && c0 + 8 <= xend && !(UP && xup) && dbg != 1 && xsC * 28 < 0x7FFFFFF0LL && !(a.dbg & 128);
+        }
+        if (fastc[PAR]) {
+            if (cl == 0) upm[PAR] = 0u;
+            const i32x4 xs = make_rsrc(xp, 0x7FFFFFF0u);
+            const unsigned so = (unsigned)cl * (unsigned)(xsC * 4);
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) xr[PAR][p][cl] = x3h_load_s(xs, xvo[p], so);
+            if (cl == 7) xp += 8 * xsC;
+            return;
+        }
         const int ci = k * 8 + cl;                                // wave-uniform
         const bool live = ci < a.Cin && dbg != 1;
         if (live && ci >= xend) next_source();                    // (a source may be a single channel: two steps at most)
@@ -258,10 +288,15 @@ __global__ __launch_bounds__(256, (X3hCfg<MT, TH>::OCC + (HI ? 1 : 0))) void con
     auto stage_lowres = [&](auto par) {
         constexpr int PAR = decltype(par)::value;
         if (upm[PAR] == 0u) return;
-        float* lq = reinterpret_cast<float*>(smem_x3h + Cfg::L_OFF) + tid;
+        // (channels of the chunk that are NOT upsampled hold this thread's full-resolution pixel here: stored too, never read back)
+        if (tid < Cfg::LSLOT) {
+            vr_f32x4h lo4, hi4;
 #pragma unroll
-        for (int cl = 0; cl < 8; ++cl)
-            if (((upm[PAR] >> cl) & 1u) && tid < Cfg::LSLOT) lq[cl * Cfg::LSLOT] = xr[PAR][0][cl];
+            for (int j = 0; j < 4; ++j) { lo4[j] = xr[PAR][0][j]; hi4[j] = xr[PAR][0][4 + j]; }
+            char* lq = smem_x3h + Cfg::L_OFF + tid * 32;
+            *reinterpret_cast<vr_f32x4h*>(lq) = lo4;
+            *reinterpret_cast<vr_f32x4h*>(lq + 16) = hi4;
+        }
     };
     // ---- the running power-of-two shift of the pixels (header): x' = x * 2^sh ----
     int sh = 0, shlo = 0;                                          // (shlo: the shift the largest chunk so far asked for)
@@ -302,13 +337,30 @@ __global__ __launch_bounds__(256, (X3hCfg<MT, TH>::OCC + (HI ? 1 : 0))) void con
                     // last row / column, where their weight is exactly 0 and the staging tile holds zeros
                     const char* lq = smem_x3h + Cfg::L_OFF + (lidx[p] >= 0 ? lidx[p] : 0);
                     const float h1l = lh[p], h0l = 1.f - h1l, w1l = lw_[p], w0l = 1.f - w1l;
+                    if (upm[PAR] == 0xFFu) {
+                        // the whole chunk is upsampled (64 of the 65 upsampled channels of a dec1 layer): eight 16-byte reads up front,
+                        // then straight-line arithmetic -- no per-channel branch, the LDS latency is paid once per pixel
+                        vr_f32x4h nb[4][2];
 #pragma unroll
-                    for (int cl = 0; cl < 8; ++cl) {
-                        if ((upm[PAR] >> cl) & 1u) {
-                            const float* q = reinterpret_cast<const float*>(lq + cl * Cfg::LSLOT * 4);
-                            const float v00 = q[0], v01 = q[1], v10 = q[Cfg::LW], v11 = q[Cfg::LW + 1];
+                        for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+                            for (int hf = 0; hf < 2; ++hf)
+                                nb[q4][hf] = *reinterpret_cast<const vr_f32x4h*>(lq + ((q4 >> 1) * Cfg::LW + (q4 & 1)) * 32 + hf * 16);
+#pragma unroll
+                        for (int cl = 0; cl < 8; ++cl) {
+                            const float v00 = nb[0][cl >> 2][cl & 3], v01 = nb[1][cl >> 2][cl & 3], v10 = nb[2][cl >> 2][cl & 3], v11 = nb[3][cl >> 2][cl & 3];
                             const float v = h0l * (w0l * v00 + w1l * v01) + h1l * (w0l * v10 + w1l * v11);
                             xr[PAR][p][cl] = lidx[p] >= 0 ? v : 0.f;
+                        }
+                    } else {
+#pragma unroll
+                        for (int cl = 0; cl < 8; ++cl) {
+                            if ((upm[PAR] >> cl) & 1u) {
+                                const float* q = reinterpret_cast<const float*>(lq) + cl;
+                                const float v00 = q[0], v01 = q[8], v10 = q[Cfg::LW * 8], v11 = q[Cfg::LW * 8 + 8];
+                                const float v = h0l * (w0l * v00 + w1l * v01) + h1l * (w0l * v10 + w1l * v11);
+                                xr[PAR][p][cl] = lidx[p] >= 0 ? v : 0.f;
+                            }
                         }
                     }
                 }
