@@ -41,13 +41,6 @@ __device__ __forceinline__ float x3h_load(i32x4 rsrc, int voff) {
     asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(rsrc) : "memory");
     return v;
 }
-// the same with a scalar byte offset on top (not part of the descriptor's range check on gfx9: a padding pixel, vector offset 2^31,
-// still reads 0) -- one descriptor and one vector offset serve the eight channels of a chunk
-__device__ __forceinline__ float x3h_load_s(i32x4 rsrc, int voff, unsigned soff) {
-    float v;
-    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-    return v;
-}
 // s_waitcnt vmcnt(N) that the uses of the eight registers cannot be scheduled across
 template <int N>
 __device__ __forceinline__ void x3h_wait8(float (&r)[8]) {
@@ -241,28 +234,11 @@ __global__ __launch_bounds__(256, (X3hCfg<MT, TH>::OCC + (HI ? 1 : 0))) void con
     // Every chunk issues the SAME number of loads (channels beyond Cin read through an empty descriptor), so the hand-placed
     // s_waitcnt counts are compile-time constants.
     float xr[2][NPASS][8];
-    // Round 5: a chunk whose eight channels are all live, all in the CURRENT source and not upsampled -- nearly every chunk -- takes a
-    // short path: one descriptor on the chunk's first channel plane, channel cl at scalar offset cl * (channel stride); the general
-    // path below costs ~30 scalar instructions and several branches per channel (the ISA of the chunk loop had 660 scalar instructions
-    // beside 56 matrix instructions).  Same number of loads in the same order either way: the hand-placed waits do not change.
-    bool fastc[2] = {false, false};
+    // (Round 5, measured and reverted -- as in round 4: a short path for chunks whose eight channels are live, in one source and not
+    // upsampled -- one descriptor per chunk, channel cl at a scalar offset, ~15 instead of ~50 instructions per channel -- made the kernel
+    // 6 % SLOWER (conv_x3h 4.90 -> 5.22 ms per inference step): the scalar bookkeeping is not what the waves wait for.)
     auto load_channel = [&](int k, int cl, auto par) {
         constexpr int PAR = decltype(par)::value;
-        if (cl == 0) {
-            const int c0 = k * 8;
-            if (c0 < a.Cin && dbg != 1 && c0 >= xend) next_source();
-            if (c0 < a.Cin && dbg != 1 && c0 >= xend) next_source();
-            fastc[PAR] = c0 + 8 <= a.Cin && c0 + 8 <= xend && !(UP && xup) && dbg != 1 && xsC * 28 < 0x7FFFFFF0LL && !(a.dbg & 128);
-        }
-        if (fastc[PAR]) {
-            if (cl == 0) upm[PAR] = 0u;
-            const i32x4 xs = make_rsrc(xp, 0x7FFFFFF0u);
-            const unsigned so = (unsigned)cl * (unsigned)(xsC * 4);
-#pragma unroll
-            for (int p = 0; p < NPASS; ++p) xr[PAR][p][cl] = x3h_load_s(xs, xvo[p], so);
-            if (cl == 7) xp += 8 * xsC;
-            return;
-        }
         const int ci = k * 8 + cl;                                // wave-uniform
         const bool live = ci < a.Cin && dbg != 1;
         if (live && ci >= xend) next_source();                    // (a source may be a single channel: two steps at most)
