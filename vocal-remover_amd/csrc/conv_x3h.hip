@@ -66,7 +66,9 @@ __device__ __forceinline__ void split2h_pair(float x0, float x1, float s, int& p
 // 2^e as a float, e in [-126, 127]
 __device__ __forceinline__ float x3h_pow2(int e) { return __int_as_float((e + 127) << 23); }
 
-template <int MT, int TH>
+// UP: the launch has upsampled sources (only then the low-resolution staging tile takes LDS: without it three 64 x 8 workgroups fit a CU
+// with room to spare -- 146 KB -- where 3 x 53.3 KB = 159.8 KB sat on the edge of the 160 KB, allocation granularity unknown)
+template <int MT, int TH, bool UP = true>
 struct X3hCfg {
     static constexpr int TW = 32, CK = 8, KK = 9;
     static constexpr int TH_in = TH + 2, PW = TW + 2;           // halo tile, pixels
@@ -84,7 +86,7 @@ struct X3hCfg {
     // behind scalar branches with the LDS latency exposed each time -- 3.9 k of the 13.5 k cycles of a chunk, profiles/r05_x3h_phase_trace.txt)
     static constexpr int LROWS = TH / 2 + 3, LW = 20, LSLOT = LROWS * LW;
     static constexpr int L_OFF = P_BYTES + 2 * W_BYTES;
-    static constexpr int L_BYTES = CK * LSLOT * 4;
+    static constexpr int L_BYTES = UP ? CK * LSLOT * 4 : 0;
     static constexpr int E_OFF = L_OFF + L_BYTES;               // epilogue constants of the cout tile: bias, scale, shift, 1 / weight scale [4][MT] fp32
     static constexpr int M_OFF = E_OFF + 4 * MT * 4;            // the four wave maxima of the chunk being split (uint bits of |x|)
     static constexpr int LDS_BYTES = M_OFF + 16;
@@ -115,7 +117,7 @@ void x3h_trace_clear() {
 // HI: one more workgroup per CU than the register budget of the UP form allows (plain form only: 153 / 113 registers)
 template <int MT, int TH, bool UP, bool HI, bool TRACE = false>
 __global__ __launch_bounds__(256, (X3hCfg<MT, TH>::OCC + (HI ? 1 : 0))) void conv_x3h_kernel(const ConvArgs a) {
-    using Cfg = X3hCfg<MT, TH>;
+    using Cfg = X3hCfg<MT, TH, UP>;
     constexpr int TW = Cfg::TW, KK = Cfg::KK, PW = Cfg::PW, NSLOT = Cfg::NSLOT, NPASS = Cfg::NPASS, WM = Cfg::WM, WN = Cfg::WN,
                   PLANE = Cfg::PLANE, NWP = Cfg::NWP, NWPASS = Cfg::NWPASS;
     extern __shared__ __attribute__((aligned(16))) char smem_x3h[];
@@ -665,7 +667,7 @@ void launch_x3h_weights_batched(const X3WDesc* d_descs, int n, long long max_ele
 
 template <int MT, int TH, bool UP, bool HI, bool TRACE = false>
 static void x3h_launch_up(const ConvArgs& a, hipStream_t st) {
-    using Cfg = X3hCfg<MT, TH>;
+    using Cfg = X3hCfg<MT, TH, UP>;
     auto kern = conv_x3h_kernel<MT, TH, UP, HI, TRACE>;
     static std::atomic<unsigned long long> attr_done{0};
     ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES);
