@@ -18,7 +18,11 @@ struct DevBuf {
     DevBuf() = default;
     explicit DevBuf(size_t n_) : n(n_) {
         VR_HIP(hipMalloc(&p, (n ? n : 1) * sizeof(float)));
+        // hipMemset on device memory returns before the fill has run, and the fill is on the NULL stream: the kernels of these hooks
+        // run on the handle's non-blocking stream, which does not order against it -- wait here, or a late fill wipes a kernel's output
+        // (seen once in round 5: test_gpu_hazard 'rows' victim off by whole values beside a busy aggressor)
         VR_HIP(hipMemset(p, 0, (n ? n : 1) * sizeof(float)));
+        VR_HIP(hipStreamSynchronize(nullptr));
     }
     DevBuf(const float* host, size_t n_) : n(n_) {
         VR_HIP(hipMalloc(&p, (n ? n : 1) * sizeof(float)));
