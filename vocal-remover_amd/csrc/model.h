@@ -181,11 +181,7 @@ public:
     // eval mode, second lane: the crops of a batch are independent, so separate() runs the two halves
     // of the batch as two concurrent chains (own streams, own workspace); the tail of one chain's
     // kernels and its memory-bound kernels (upsample, LSTM, copies) overlap the other chain's convs.
-    // (aux: three more streams per lane for the four independent ASPP branch convs -- round 5; shared by the lane's two band chains)
-    struct Lane { hipStream_t main = nullptr, side = nullptr; hipEvent_t fork = nullptr, join = nullptr, start = nullptr, done = nullptr; Arena ws;
-                  hipStream_t aux[3] = {nullptr, nullptr, nullptr}; hipEvent_t aux_fork = nullptr, aux_join[3] = {nullptr, nullptr, nullptr}; };
-    hipStream_t aux[3] = {nullptr, nullptr, nullptr};    // lane A's
-    hipEvent_t aux_fork = nullptr, aux_join[3] = {nullptr, nullptr, nullptr};
+    struct Lane { hipStream_t main = nullptr, side = nullptr; hipEvent_t fork = nullptr, join = nullptr, start = nullptr, done = nullptr; Arena ws; };
     std::vector<Lane> lanes;                             // the additional lanes (VR_LANES - 1, default 1)
     void swap_lane(int i);
 

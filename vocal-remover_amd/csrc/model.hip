@@ -134,16 +134,6 @@ Model::Model(int device_, int n_fft_, int hop_, int nout_, int nout_lstm_)
         VR_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
         VR_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         VR_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-        static const bool aspp_fan = !(getenv("VR_ASPP_FAN") && atoi(getenv("VR_ASPP_FAN")) == 0);
-        auto make_aux = [&](hipStream_t (&s)[3], hipEvent_t& f, hipEvent_t (&j)[3]) {
-            if (!aspp_fan) return;
-            VR_HIP(hipEventCreateWithFlags(&f, hipEventDisableTiming));
-            for (int i = 0; i < 3; ++i) {
-                VR_HIP(hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking));
-                VR_HIP(hipEventCreateWithFlags(&j[i], hipEventDisableTiming));
-            }
-        };
-        make_aux(aux, aux_fork, aux_join);
         if (!getenv("VR_NO_SPLIT_BATCH")) {
             int k = getenv("VR_LANES") ? atoi(getenv("VR_LANES")) : 2;
             k = k < 1 ? 1 : (k > 4 ? 4 : k);
@@ -155,7 +145,6 @@ Model::Model(int device_, int n_fft_, int hop_, int nout_, int nout_lstm_)
                 VR_HIP(hipEventCreateWithFlags(&l.join, hipEventDisableTiming));
                 VR_HIP(hipEventCreateWithFlags(&l.start, hipEventDisableTiming));
                 VR_HIP(hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
-                make_aux(l.aux, l.aux_fork, l.aux_join);
             }
         }
     }
@@ -265,12 +254,8 @@ Model::~Model() {
         hipStreamSynchronize(l.main); hipStreamSynchronize(l.side);
         hipStreamDestroy(l.main); hipStreamDestroy(l.side);
         hipEventDestroy(l.fork); hipEventDestroy(l.join); hipEventDestroy(l.start); hipEventDestroy(l.done);
-        for (int i = 0; i < 3; ++i) if (l.aux[i]) { hipStreamSynchronize(l.aux[i]); hipStreamDestroy(l.aux[i]); hipEventDestroy(l.aux_join[i]); }
-        if (l.aux_fork) hipEventDestroy(l.aux_fork);
         hipFree(l.ws.base);
     }
-    for (int i = 0; i < 3; ++i) if (aux[i]) { hipStreamSynchronize(aux[i]); hipStreamDestroy(aux[i]); hipEventDestroy(aux_join[i]); }
-    if (aux_fork) hipEventDestroy(aux_fork);
     if (side_stream) { hipStreamSynchronize(side_stream); hipStreamDestroy(side_stream); hipEventDestroy(ev_fork); hipEventDestroy(ev_join); }
     if (stream) hipStreamDestroy(stream);
 }
@@ -534,8 +519,6 @@ void Model::swap_lane(int i) {
     std::swap(ev_fork, l.fork);
     std::swap(ev_join, l.join);
     std::swap(ws, l.ws);
-    for (int i = 0; i < 3; ++i) { std::swap(aux[i], l.aux[i]); std::swap(aux_join[i], l.aux_join[i]); }
-    std::swap(aux_fork, l.aux_fork);
 }
 
 void Model::ensure_io(size_t bytes) {
@@ -971,25 +954,9 @@ Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, co
     static const bool aspp_fork = !getenv("VR_NO_ASPP_FORK");
     const bool afk = aspp_fork && !serial && !training && !dry && !profiling && side_stream != nullptr && !band_fork_active;
     hipStream_t aspp_main = stream;
-    // Round 5: with the lane's three auxiliary streams every branch gets its own stream, in every stage (the two-stream fork below only
-    // runs in stage 3, where the side stream is idle): four launches of 350-700 workgroups each at 1/16 resolution fill the CUs together.
-    const bool fan = !serial && !training && !dry && !profiling && aux[0] != nullptr;
-    if (fan) {
-        VR_HIP(hipEventRecord(aux_fork, aspp_main));
-        for (int i = 0; i < 3; ++i) VR_HIP(hipStreamWaitEvent(aux[i], aux_fork, 0));
-        for (int j = 0; j < 4; ++j) {
-            Tensor v = cat4;
-            v.C = C8;
-            v.p = cat4.p + (long long)j * C8 * cat4.sC;
-            stream = j == 0 ? aspp_main : aux[j - 1];
-            try { run_conv(*branch[j], {SrcSpec{x5}}, N, &v, nullptr, false); } catch (...) { stream = aspp_main; throw; }
-        }
-        stream = aspp_main;
-        for (int i = 0; i < 3; ++i) {
-            VR_HIP(hipEventRecord(aux_join[i], aux[i]));
-            VR_HIP(hipStreamWaitEvent(aspp_main, aux_join[i], 0));
-        }
-    } else {
+    // (Round 5, measured and removed: every branch on its own stream -- three auxiliary streams per lane, in every stage -- made the
+    // inference step 12.4 ms instead of 8.65, also with 8 or 16 hardware queues: each extra fork / join pair costs more than the overlap
+    // of four ~60 us kernels returns.  Two streams, stage 3 only, is the measured optimum.)
     if (afk) {
         hipEvent_t ef = ev_fork;
         VR_HIP(hipEventRecord(ef, aspp_main));
@@ -1008,7 +975,6 @@ Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, co
         hipEvent_t ej = ev_join;
         VR_HIP(hipEventRecord(ej, side_stream));
         VR_HIP(hipStreamWaitEvent(aspp_main, ej, 0));
-    }
     }
     SrcSpec s1{f1};
     s1.bcastH = x5.H;          // bilinear from H=1 with align_corners=True is a broadcast along H
