@@ -225,7 +225,6 @@ def roofline_from_rows(rows, pmc_name, conv_totals):
     for c in classes.values():
         ms, pipe = c['ms_per_step'], c.pop('pipe')
         # executed products per fp32 product: six on the bf16 pipe (conv_x3); conv_x3h issues 14 16-deep instructions per 9 taps x 8 channels
-        # (wgrad_x3h: three instructions per 16 pixels, tap and 32 x 32 block = 3 executed products per product)
         mult = {'bf16': 6.0, 'f16x3': 14 * 16 / 72.0, 'f16w': 3.0}.get(pipe, 1.0)
         pk = {'bf16': BF16_MFMA_PEAK_TFLOPS, 'f16x3': BF16_MFMA_PEAK_TFLOPS, 'f16w': BF16_MFMA_PEAK_TFLOPS, 'fp32': FP32_MFMA_PEAK_TFLOPS}.get(pipe)
         t_flop = (mult * c['flops'] / (pk * 1e12) * 1e3) if pk else 0.0          # ms at the matrix-pipe peak
@@ -709,7 +708,7 @@ def main():
                          'once, summed by RCCL in bf16, widened back); activations, master weights, accumulation and Adam stay fp32',
                 'what_it_is_not': 'a bf16-STORAGE pipeline: bf16 operands without the split lose the gradient direction on this net (cosine 0.37 vs fp32 at '
                                   'batch 16, tests/test_gpu_b16.py) and storing the three bf16 planes (6 B per element) measured no faster than fp32 storage '
-                                  '(conv_x3p.hip, DESIGN.md section 3)',
+                                  '(tools/experiments/conv_x3p.hip, DESIGN.md section 3)',
                 'parity': 'tests/test_gpu_b16.py::test_b16_configs4_slice_vs_fp32: loss 1e-4 relative, global gradient cosine >= 0.99, per-tensor median >= 0.98 against '
                           'mfma_mode 0 with the fp32 bucket at batch 16'}
             out['fp32_mfma'] = {
