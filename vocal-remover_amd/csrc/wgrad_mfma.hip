@@ -22,7 +22,12 @@ struct WgCfg {
     static constexpr int TP = TH * TW;                 // pixels per tile (= MFMA K extent per tile)
     static constexpr int TH_in = (TH - 1) * S + (KS - 1) * DH + 1;
     static constexpr int TW_in = (TW - 1) * S + (KS - 1) * DW + 1;
-    static constexpr int CS = (TH_in * TW_in) | 1;     // odd channel pitch: 32 lanes = 32 channels -> 32 banks
+    // Dilated layers (round 5): with dilation above the tile height the haloed window is mostly rows no tap of this tile reads
+    // (TH = 4, dilation 12: 28 rows for 4); three TH-row windows, one per kernel row, hold everything the nine taps touch --
+    // 336 instead of 784 staged elements per channel at dilation 12 (288 / 480 at 8), and three workgroups per CU instead of one.
+    static constexpr bool TAPROWS = KS == 3 && S == 1 && (KS - 1) * DH + TH > KS * TH;
+    static constexpr int XROWS = TAPROWS ? KS * TH : TH_in;
+    static constexpr int CS = (XROWS * TW_in) | 1;     // odd channel pitch: 32 lanes = 32 channels -> 32 banks
     static constexpr int DSs = TP + 1;                 // odd cout pitch
     static constexpr int NT = (KK * MB + 3) / 4;       // accumulator tiles per wave
     static constexpr int XS = 32 * CS;
@@ -62,7 +67,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradArgs a) {
         mb_i[i] = t / KK;
         tap_i[i] = t % KK;
         moff_i[i] = mb_i[i] * 32 * DSs;
-        toff_i[i] = (tap_i[i] / KS) * DH * TW_in + (tap_i[i] % KS) * DW;
+        toff_i[i] = (tap_i[i] / KS) * (Cfg::TAPROWS ? TH : DH) * TW_in + (tap_i[i] % KS) * DW;
     }
     f32x16 acc[NT];
 #pragma unroll
@@ -106,8 +111,15 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradArgs a) {
             }
         }
         // ---- input tile: Xs[ci][haloed tile] -------------------------------------------------------------
-        stage_input_chunk<TH_in, TW_in, TW_in, CS, 32, 4>(a.in, Xs, c0, n, h0 * S - a.in.pad_h, w0 * S - a.in.pad_w,
-                                                           wave, lane);
+        if constexpr (Cfg::TAPROWS) {
+#pragma unroll
+            for (int kh = 0; kh < KS; ++kh)
+                stage_input_chunk<TH, TW_in, TW_in, CS, 32, 4>(a.in, Xs + kh * TH * TW_in, c0, n, h0 - a.in.pad_h + kh * DH, w0 - a.in.pad_w,
+                                                               wave, lane);
+        } else {
+            stage_input_chunk<TH_in, TW_in, TW_in, CS, 32, 4>(a.in, Xs, c0, n, h0 * S - a.in.pad_h, w0 * S - a.in.pad_w,
+                                                               wave, lane);
+        }
         __syncthreads();
         // ---- MFMA over the tile's pixels ---------------------------------------------------------------------
 #pragma unroll 2
