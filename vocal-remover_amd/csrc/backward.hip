@@ -279,18 +279,43 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ dhi, int N, int C,
 // the (2*8+3) x (2*32+3) patch of the high-resolution gradient that can touch it is staged once (coalesced rows), the
 // 5 x 5 separable gather then runs out of LDS -- every dhi element is fetched from HBM once per tile instead of up to
 // 25 times through the caches.
+// VEC (round 5): the patch is staged with ALIGNED 16-byte loads -- columns [2 j0 - 4, 2 j0 + 2 TJ + 4), 18 quads per row, 342 loads per
+// tile instead of 1273 four-byte ones on rows that start two floats off a 16-byte boundary (needs 2 W % 4 == 0 and an aligned dhi).
+template <bool VEC>
 __global__ __launch_bounds__(256) void upsample_bwd_tiled_kernel(const float* __restrict__ dhi, int C, int H, int W, float rh,
                                                                  float rw, int tiles_w, int tiles_per_plane,
                                                                  float* __restrict__ glo, long long gN, long long gC,
                                                                  long long gH, int accumulate) {
-    constexpr int TI = 8, TJ = 32, PH = 2 * TI + 3, PW = 2 * TJ + 3, PP = PW + 1;
-    __shared__ float patch[PH * PP];
+    constexpr int TI = 8, TJ = 32, PH = 2 * TI + 3, PW = 2 * TJ + 3, PP = VEC ? 2 * TJ + 12 : PW + 1, XO = VEC ? 2 : 0;
+    __shared__ __attribute__((aligned(16))) float patch[PH * PP];
     const int plane = blockIdx.x / tiles_per_plane;          // n * C + c
     const int trem = blockIdx.x - plane * tiles_per_plane;
     const int i0 = (trem / tiles_w) * TI, j0 = (trem % tiles_w) * TJ;
     const int H2 = 2 * H, W2 = 2 * W;
     const float* src = dhi + (long long)plane * H2 * W2;
     const int hb = 2 * i0 - 2, wb = 2 * j0 - 2;
+    if constexpr (VEC) {
+        constexpr int QR = (2 * TJ + 8) / 4, NV = (PH * QR + 255) / 256;       // 18 quads per row: patch column 4 q <-> w = wb - 2 + 4 q
+        float4 pv4[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int e = threadIdx.x + 256 * k;
+            const int ec = e < PH * QR ? e : PH * QR - 1;
+            const int r = ec / QR, q = ec - r * QR;
+            int h = hb + r, w = wb - 2 + 4 * q;
+            h = h < 0 ? 0 : (h >= H2 ? H2 - 1 : h);
+            w = w < 0 ? 0 : (w > W2 - 4 ? W2 - 4 : w);
+            pv4[k] = *reinterpret_cast<const float4*>(src + (long long)h * W2 + w);
+        }
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int e = threadIdx.x + 256 * k;
+            const int r = e / QR, q = e - r * QR;
+            const int h = hb + r, w = wb - 2 + 4 * q;
+            if (e < PH * QR)
+                *reinterpret_cast<float4*>(patch + r * PP + 4 * q) = (h >= 0 && h < H2 && w >= 0 && w < W2) ? pv4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    } else {
     // all loads of the thread issued before the first use: clamped addresses, masked afterwards (a load behind its own guard gets
     // a vmcnt(0) from hipcc -- five serial memory round trips per thread)
     constexpr int NL = (PH * PW + 255) / 256;
@@ -311,6 +336,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_tiled_kernel(const float* __
         const int r = e / PW, q = e - r * PW;
         const int h = hb + r, w = wb + q;
         if (e < PH * PW) patch[r * PP + q] = (h >= 0 && h < H2 && w >= 0 && w < W2) ? pv[k] : 0.f;
+    }
     }
     __syncthreads();
     const int ti = threadIdx.x >> 5, tj = threadIdx.x & 31;
@@ -342,7 +368,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_tiled_kernel(const float* __
         }
         ww[d] = u;
     }
-    const float* pr = patch + (2 * ti) * PP + 2 * tj;
+    const float* pr = patch + (2 * ti) * PP + 2 * tj + XO;
     float acc = 0.f;
 #pragma unroll
     for (int dh = 0; dh < 5; ++dh) {
@@ -366,8 +392,13 @@ void launch_upsample_bwd(const float* dhi, int N, int C, int H, int W, float* gl
         const int tiles_w = (W + 31) / 32, tiles_h = (H + 7) / 8;
         const long long blocks = (long long)N * C * tiles_h * tiles_w;
         if (blocks < 0x7FFFFFFFLL) {
-            VR_LAUNCH(upsample_bwd_tiled_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dhi, C, H, W, rh, rw, tiles_w,
-                               tiles_h * tiles_w, glo, gN, gC, gH, accumulate);
+            static const bool vec_on = !(getenv("VR_UPBWD_VEC") && atoi(getenv("VR_UPBWD_VEC")) == 0);
+            if (vec_on && (W & 1) == 0 && W >= 2 && (reinterpret_cast<uintptr_t>(dhi) & 15) == 0)
+                VR_LAUNCH(upsample_bwd_tiled_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, dhi, C, H, W, rh, rw, tiles_w,
+                                   tiles_h * tiles_w, glo, gN, gC, gH, accumulate);
+            else
+                VR_LAUNCH(upsample_bwd_tiled_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, dhi, C, H, W, rh, rw, tiles_w,
+                                   tiles_h * tiles_w, glo, gN, gC, gH, accumulate);
             VR_HIP(hipGetLastError());
             return;
         }
