@@ -353,6 +353,69 @@ __global__ __launch_bounds__(256) void upsample2x_rows_kernel(Tensor x, float* _
     reinterpret_cast<float4*>(out + ((long long)pc * H2 + hi) * W2)[q] = make_float4(o[0], o[1], o[2], o[3]);
 }
 
+// LDS form of the row-tiled kernel (round 5): a workgroup makes 256 >> qp consecutive output rows of ONE plane; the source rows under
+// them (at most half as many + 2) are fetched once with aligned 16-byte loads, BatchNorm affine + activation applied on the way in, and
+// every thread then takes its eight source values from LDS -- one global load per thread at most instead of eight 4-byte ones.
+// Same arithmetic, same order as upsample2x_rows_kernel (bit-equal results).  Needs W % 4 == 0, 16-byte aligned rows, 2 H % rows == 0.
+__global__ __launch_bounds__(256) void upsample2x_lds_kernel(Tensor x, float* __restrict__ out, float rh, float rw, int qp_log2) {
+    __shared__ __attribute__((aligned(16))) float L[1024];                   // (128 >> qp + 2) rows x W <= 768 floats
+    const int W2 = 2 * x.W, H2 = 2 * x.H;
+    const int rpb = 256 >> qp_log2;
+    const long long row0 = (long long)blockIdx.x * rpb;
+    const int pc = (int)(row0 / H2);                                        // n * C + c
+    const int hi0 = (int)(row0 - (long long)pc * H2);
+    const int c = pc % x.C, n = pc / x.C;
+    const int hmin = (int)(rh * (float)hi0);
+    int hmax = (int)(rh * (float)(hi0 + rpb - 1)) + 1;
+    hmax = hmax < x.H - 1 ? hmax : x.H - 1;
+    const int nsrc = hmax - hmin + 1, Q = x.W >> 2;
+    const float* base = x.p + (long long)n * x.sN + (long long)c * x.sC;
+    for (int e = threadIdx.x; e < nsrc * Q; e += 256) {
+        const int r = e / Q, q = e - r * Q;
+        const int h = hmin + r;
+        const float* af = (h < x.hsplit) ? x.aff0 : x.aff1;
+        const float sc = af ? af[2 * c] : 1.f, sh = af ? af[2 * c + 1] : 0.f;
+        const float4 v = *reinterpret_cast<const float4*>(base + (long long)h * x.sH + 4 * q);
+        *reinterpret_cast<float4*>(L + r * x.W + 4 * q) = make_float4(act1(fmaf(v.x, sc, sh), x.slope), act1(fmaf(v.y, sc, sh), x.slope),
+                                                                      act1(fmaf(v.z, sc, sh), x.slope), act1(fmaf(v.w, sc, sh), x.slope));
+    }
+    __syncthreads();
+    const int q = threadIdx.x & ((1 << qp_log2) - 1);
+    const int hi = hi0 + (threadIdx.x >> qp_log2);
+    if (4 * q >= W2) return;
+    const float h1r = rh * (float)hi;
+    const int h1 = (int)h1r;
+    const int h1p = (h1 < x.H - 1) ? 1 : 0;
+    const float h1l = h1r - (float)h1, h0l = 1.f - h1l;
+    const float* r0 = L + (h1 - hmin) * x.W;
+    const float* r1 = r0 + h1p * x.W;
+    const float post = x.post ? x.post[n * x.C + c] : 1.f;
+    const int wb = (int)(rw * (float)(4 * q));
+    float a[4], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ws = wb + j < x.W ? wb + j : x.W - 1;
+        a[j] = r0[ws];
+        b[j] = r1[ws];
+    }
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int wi = 4 * q + j;
+        const float w1r = rw * (float)wi;
+        const int w1 = (int)w1r;
+        const int w1p = (w1 < x.W - 1) ? 1 : 0;
+        const float w1l = w1r - (float)w1, w0l = 1.f - w1l;
+        const int d = w1 - wb;                                   // 0, 1 or 2
+        const float v00 = d == 0 ? a[0] : (d == 1 ? a[1] : a[2]);
+        const float v01 = w1p ? (d == 0 ? a[1] : (d == 1 ? a[2] : a[3])) : v00;
+        const float v10 = d == 0 ? b[0] : (d == 1 ? b[1] : b[2]);
+        const float v11 = w1p ? (d == 0 ? b[1] : (d == 1 ? b[2] : b[3])) : v10;
+        o[j] = (h0l * (w0l * v00 + w1l * v01) + h1l * (w0l * v10 + w1l * v11)) * post;
+    }
+    reinterpret_cast<float4*>(out + ((long long)pc * H2 + hi) * W2)[q] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 void launch_upsample2x(const Tensor& x, float* out, hipStream_t st) {
     const float rh = (x.H > 0) ? (float)(x.H - 1) / (float)(2 * x.H - 1) : 0.f;
     const float rw = (x.W > 0) ? (float)(x.W - 1) / (float)(2 * x.W - 1) : 0.f;
@@ -365,6 +428,13 @@ void launch_upsample2x(const Tensor& x, float* out, hipStream_t st) {
         int qp = 2;                                            // threads per row: power of two >= quads, 4 .. 256
         while ((1 << qp) < quads && qp < 8) ++qp;
         const int rpb = 256 >> qp;
+        static const bool lds_on = !(getenv("VR_UP_LDS") && atoi(getenv("VR_UP_LDS")) == 0);
+        if (lds_on && qp <= 7 && (x.W & 3) == 0 && (x.sH & 3) == 0 && (x.sC & 3) == 0 && (x.sN & 3) == 0 && (2 * x.H) % rpb == 0 &&
+            (reinterpret_cast<uintptr_t>(x.p) & 15) == 0 && (128 / (1 << qp) + 3) * x.W <= 1024) {
+            VR_LAUNCH(upsample2x_lds_kernel, dim3((unsigned)(nrows / rpb)), dim3(256), 0, st, x, out, rh, rw, qp);
+            VR_HIP(hipGetLastError());
+            return;
+        }
         VR_LAUNCH(upsample2x_rows_kernel, dim3((unsigned)((nrows + rpb - 1) / rpb), qp >= 8 ? (quads + 255) / 256 : 1), dim3(256),
                            0, st, x, out, rh, rw, qp, nrows);
         VR_HIP(hipGetLastError());
