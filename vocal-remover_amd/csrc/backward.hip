@@ -338,36 +338,35 @@ __global__ __launch_bounds__(256) void upsample_bwd_tiled_kernel(const float* __
         if (e < PH * PW) patch[r * PP + q] = (h >= 0 && h < H2 && w >= 0 && w < W2) ? pv[k] : 0.f;
     }
     }
+    // the 5 row weights of the tile's 8 rows and the 5 column weights of its 32 columns: 200 values computed once per workgroup and
+    // shared through LDS (round 5: every thread used to derive its own ten -- ~80 VALU instructions per output element)
+    __shared__ float whs[TI * 5], wws[TJ * 5];
+    if (threadIdx.x < TI * 5 + TJ * 5) {
+        const bool isrow = threadIdx.x < TI * 5;
+        const int e = isrow ? threadIdx.x : threadIdx.x - TI * 5;
+        const int t = e / 5, d = e - t * 5;
+        const int o = (isrow ? i0 : j0) + t;                    // low-resolution row / column
+        const int hh = 2 * o - 2 + d;                          // high-resolution row / column that may contribute
+        const int L = isrow ? H : W, L2 = 2 * L;
+        const float rr = isrow ? rh : rw;
+        float v = 0.f;
+        if (hh >= 0 && hh < L2) {
+            const float h1r = rr * (float)hh;
+            const int h1 = (int)h1r;
+            const int h1p = (h1 < L - 1) ? 1 : 0;
+            const float l1 = h1r - (float)h1;
+            if (h1 == o) v += 1.f - l1;
+            if (h1 + h1p == o) v += l1;
+        }
+        (isrow ? whs : wws)[e] = v;
+    }
     __syncthreads();
     const int ti = threadIdx.x >> 5, tj = threadIdx.x & 31;
     const int i = i0 + ti, j = j0 + tj;
     if (i >= H || j >= W) return;
     float wh[5], ww[5];
 #pragma unroll
-    for (int d = 0; d < 5; ++d) {
-        const int h = 2 * i - 2 + d;
-        float v = 0.f;
-        if (h >= 0 && h < H2) {
-            const float h1r = rh * (float)h;
-            const int h1 = (int)h1r;
-            const int h1p = (h1 < H - 1) ? 1 : 0;
-            const float l1 = h1r - (float)h1;
-            if (h1 == i) v += 1.f - l1;
-            if (h1 + h1p == i) v += l1;
-        }
-        wh[d] = v;
-        const int w = 2 * j - 2 + d;
-        float u = 0.f;
-        if (w >= 0 && w < W2) {
-            const float w1r = rw * (float)w;
-            const int w1 = (int)w1r;
-            const int w1p = (w1 < W - 1) ? 1 : 0;
-            const float m1 = w1r - (float)w1;
-            if (w1 == j) u += 1.f - m1;
-            if (w1 + w1p == j) u += m1;
-        }
-        ww[d] = u;
-    }
+    for (int d = 0; d < 5; ++d) { wh[d] = whs[ti * 5 + d]; ww[d] = wws[tj * 5 + d]; }
     const float* pr = patch + (2 * ti) * PP + 2 * tj + XO;
     float acc = 0.f;
 #pragma unroll
