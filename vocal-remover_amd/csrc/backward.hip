@@ -169,6 +169,32 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(BnBwdArgs a) {
     *reinterpret_cast<float4*>(a.g + off) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
+// pass 2 with the plane index (n, c) on blockIdx.y (round 5): one division per thread instead of three by run-time values
+__global__ __launch_bounds__(256) void bn_bwd_apply4p_kernel(BnBwdArgs a, int HQ) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= HQ) return;
+    const int Q = a.W >> 2;
+    const int h = idx / Q, w = (idx - h * Q) * 4;
+    const int pc = blockIdx.y;
+    const int n = pc / a.C, c = pc - n * a.C;
+    const long long off = (long long)n * a.sN + (long long)c * a.sC + (long long)h * a.sH + w;
+    const int ca = a.aff_bcast ? 0 : c;
+    const float sc = a.aff ? a.aff[2 * ca] : 1.f, sh = a.aff ? a.aff[2 * ca + 1] : 0.f;
+    const float pm = a.post ? a.post[n * a.C + c] : 1.f;
+    float kA = 1.f, kB = 0.f, kC = 0.f;
+    if (a.coef) { kA = a.coef[3 * c]; kB = a.coef[3 * c + 1]; kC = a.coef[3 * c + 2]; }
+    const float4 z4 = *reinterpret_cast<const float4*>(a.z + off);
+    const float4 g4 = *reinterpret_cast<const float4*>(a.g + off);
+    const float zz[4] = {z4.x, z4.y, z4.z, z4.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float dy = gg[j] * pm * dact(fmaf(zz[j], sc, sh), a.slope);
+        o[j] = a.coef ? fmaf(kA, dy, fmaf(kB, zz[j], kC)) : dy;
+    }
+    *reinterpret_cast<float4*>(a.g + off) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
     const long long total = (long long)a.N * a.C * a.H * a.W;
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -211,7 +237,11 @@ void launch_bn_bwd(const BnBwdArgs& a, hipStream_t st) {
     const bool vec = (a.W & 3) == 0 && (a.sH & 3) == 0 && (a.sC & 3) == 0 && (a.sN & 3) == 0 &&
                      ((reinterpret_cast<uintptr_t>(a.z) | reinterpret_cast<uintptr_t>(a.g)) & 15) == 0;
     prof_note(0.0, 12.0 * elems);                            // reads z and g, writes g
-    if (vec) VR_LAUNCH(bn_bwd_apply4_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, a);
+    const long long HQ = (long long)a.H * (a.W >> 2), planes = (long long)a.N * a.C;
+    static const bool planes_on = !(getenv("VR_MAT_PLANES") && atoi(getenv("VR_MAT_PLANES")) == 0);
+    if (vec && planes_on && planes <= 65535 && HQ >= 256 && HQ < (1LL << 30))
+        VR_LAUNCH(bn_bwd_apply4p_kernel, dim3((unsigned)((HQ + 255) / 256), (unsigned)planes), dim3(256), 0, st, a, (int)HQ);
+    else if (vec) VR_LAUNCH(bn_bwd_apply4_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, a);
     else VR_LAUNCH(bn_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
     VR_HIP(hipGetLastError());
 }
