@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'vocal-remover_amd', 'csrc')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 AUDIT = os.path.join(ROOT, 'tools', 'asm_inflight_audit.py')
+AUDIT2 = os.path.join(ROOT, 'tools', 'asm_inflight_audit2.py')
 
 
 def _asm(tmp_path, src):
@@ -49,3 +50,7 @@ def test_no_instruction_touches_an_in_flight_asm_load(tmp_path):
         assert len(rows) == 1, out[-2000:]
         (name, (loads, bad)), = rows.items()
         assert loads >= 100 and bad == 0, (name, loads, bad, out[-2000:])
+        # round 6: the second audit follows the registers by NAME (x3h_wait8 lists the registers it releases in a `; landed` comment), no
+        # vmcnt arithmetic: it is the tool that caught hipcc copying in-flight registers of the parked ping-pong kernel
+        r = subprocess.run([sys.executable, AUDIT2, asm, 'conv_x3h_kernel' + inst], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and ' 0 reports' in r.stdout, r.stdout[-2000:]

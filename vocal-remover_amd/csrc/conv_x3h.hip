@@ -30,41 +30,9 @@
 #include "conv_stage.h"
 #include "kernels.h"
 #include "lds_dma.h"
+#include "x3h_common.h"
 
 namespace vr {
-
-// The pixel loads are inline asm and their waits are placed by hand: hipcc's wait-count pass loses the issue order of loads that
-// cross a loop back edge / uniform branches and then waits for (nearly) everything, i.e. also for the loads issued for the chunk
-// after next -- the prefetch depth the register sets pay for.
-__device__ __forceinline__ float x3h_load(i32x4 rsrc, int voff) {
-    float v;
-    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(rsrc) : "memory");
-    return v;
-}
-// s_waitcnt vmcnt(N) that the uses of the eight registers cannot be scheduled across
-template <int N>
-__device__ __forceinline__ void x3h_wait8(float (&r)[8]) {
-    asm volatile("s_waitcnt vmcnt(%8)"
-                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
-                 : "n"(N) : "memory");
-}
-
-typedef _Float16 vr_f16x8 __attribute__((ext_vector_type(8)));
-typedef float vr_f32x4h __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x16 mfma_f16x16(vr_f16x8 a, vr_f16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
-// (x0, x1) * s -> packed fp16 pairs of the two planes: p1 = rne(x s), p2 = rne(x s - p1); each is ONE fp32 fma rounded once to fp16
-__device__ __forceinline__ void split2h_pair(float x0, float x1, float s, int& p1, int& p2) {
-    int a, b;                                    // (mixlo leaves the other half of its destination alone; mixhi then fills it: "=v" first)
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(a) : "v"(x0), "v"(s));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(a) : "v"(x1), "v"(s));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=&v"(b) : "v"(x0), "v"(s), "v"(a));
-    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(b) : "v"(x1), "v"(s), "v"(a));
-    p1 = a; p2 = b;
-}
-// 2^e as a float, e in [-126, 127]
-__device__ __forceinline__ float x3h_pow2(int e) { return __int_as_float((e + 127) << 23); }
 
 // UP: the launch has upsampled sources (only then the low-resolution staging tile takes LDS: without it three 64 x 8 workgroups fit a CU
 // with room to spare -- 146 KB -- where 3 x 53.3 KB = 159.8 KB sat on the edge of the 160 KB, allocation granularity unknown)
@@ -423,7 +391,7 @@ __global__ __launch_bounds__(256, (X3hCfg<MT, TH>::OCC + (HI ? 1 : 0))) void con
 #pragma unroll
     for (int cl = 0; cl < 8; ++cl) load_channel(1, cl, P1{});
     wait_pixels(P0{}, std::integral_constant<int, Cfg::NXL + Cfg::NWMIN>{});      // chunk 0's pixels (weights and chunk 1 stay in flight)
-    asm volatile("" : "+v"(ecv[0]), "+v"(ecv[1]), "+v"(ecv[2]), "+v"(ecv[3]));      // (older loads: landed with them)
+    asm volatile("; landed %0 %1 %2 %3" : "+v"(ecv[0]), "+v"(ecv[1]), "+v"(ecv[2]), "+v"(ecv[3]));      // (older loads: landed with them; the comment is for tools/asm_inflight_audit2.py)
     if (tid < MT) {
         float* E = reinterpret_cast<float*>(smem_x3h + Cfg::E_OFF);
         E[tid] = ecv[0];
