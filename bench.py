@@ -283,7 +283,7 @@ def roofline_from_rows(rows, pmc_name, conv_totals):
 
 # ---- the stdout line: small enough for any tail buffer (round 4's 33 KB line overflowed the driver's 8 KB tail and went unparsed) ----
 LINE_LIMIT = 4000                  # bytes; tests/test_bench_multirank.py asserts the line stays below it
-DETAIL_PATH = os.path.join(ROOT, 'gpurun_out', 'bench_detail.json')
+DETAIL_PATH = os.environ.get('VR_BENCH_DETAIL') or os.path.join(ROOT, 'gpurun_out', 'bench_detail.json')     # (tests point it at a tmp dir)
 
 
 def _r(x, digits=5):
@@ -303,7 +303,7 @@ def compact_roofline(r, nclasses=6):
     """Scalars of a roofline object + at most `nclasses` one-line class rows [class, ms per step, bound, frac]."""
     if r is None:
         return None
-    o = {k: _r(r.get(k)) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_bytes_per_launch', 'frac_fp32_equivalent',
+    o = {k: _r(r.get(k)) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source', 'algorithmic_bytes_per_launch', 'frac_fp32_equivalent',
                                    'kernel_ms_per_step', 'conv_kernel_ms_per_step', 'launches_per_step', 'conv_launches_per_step')}
     o['kernel'] = _short_class(r['kernel'])
     o['classes'] = [[_short_class(c['class']), _r(c['ms_per_step'], 4), c['bound'], _r(c['frac'], 3)] for c in r['classes'][:nclasses]]
@@ -315,7 +315,7 @@ def compact_line(out):
     {value, ms_per_step, frac}.  Everything else (classes in full, per-kernel rows, notes) goes to gpurun_out/bench_detail.json."""
     line = {k: out[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
                                     'vs_baseline', 'dtype', 'data') if k in out}
-    line['dtype_note'] = 'fp32 storage/accumulate; 3x3 s1 convs multiply as 3 fp16 MFMA products of 2-way split operands (fp32-grade, see DESIGN.md)'
+    line['dtype_note'] = str(out.get('dtype_note', ''))[:200]                # what THIS run computed in (VR_MFMA_MODE / --bf16 change it)
     line['ms_per_step_per_rank'] = out.get('ms_per_step_per_rank')          # unrounded: ms_per_step is their MAX
     line['allreduce_ms'] = _r(out.get('allreduce_ms'), 4)
     line['config'] = {k: _r(v) for k, v in out['config'].items()}
@@ -344,7 +344,7 @@ def compact_line(out):
         cb = dict(out['cpu_baseline'])
         cb['sample'] = cb.get('sample', '')[:160]
         line['cpu_baseline'] = {k: _r(v) for k, v in cb.items()}
-    line['detail'] = 'gpurun_out/bench_detail.json'
+    line['detail'] = os.path.relpath(DETAIL_PATH, ROOT) if DETAIL_PATH.startswith(ROOT) else DETAIL_PATH
     text = json.dumps(line, separators=(',', ':'))
     # belt and braces: shed optional parts rather than ever print a line a tail buffer would cut
     for drop in (('split_bf16',), ('fp32_mfma',), ('train_bf16',), ('tta', 'classes'), ('train', 'classes'), ('roofline', 'classes')):
@@ -352,7 +352,7 @@ def compact_line(out):
             break
         tgt = line
         for k in drop[:-1]:
-            tgt = tgt.get(k, {})
+            tgt = tgt.get(k) or {}             # (a key that is present but None must not cost the line)
         tgt.pop(drop[-1], None)
         text = json.dumps(line, separators=(',', ':'))
     assert len(text) <= LINE_LIMIT, len(text)
@@ -566,31 +566,39 @@ def main():
     args = ap.parse_args()
     if args.tta:
         args.mode = 'tta'
-    # a hung communicator must end in a traceback, not in the driver's timeout: 600 s by default for N > 1 (VR_BENCH_WATCHDOG=0 turns it off)
-    watchdog = int(os.environ.get('VR_BENCH_WATCHDOG', '600' if (args.gpus > 1 or int(os.environ.get('WORLD_SIZE', '1')) > 1) else '0'))
-    if watchdog > 0:
-        import faulthandler
-        faulthandler.dump_traceback_later(watchdog, exit=True)
-
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
-        self_launch(args)
+        self_launch(args)               # (the launcher parent only waits for torchrun: no watchdog here -- it would orphan the ranks)
+    # A hung communicator must end in a traceback, not in the driver's timeout (1800 s).  The deadline is PER PHASE (build, each workload,
+    # each profiled step set, the CPU baselines): `pet()` re-arms it, so a healthy but slow 8-GPU `--mode all` run is never cut short.
+    # Default for N > 1: 900 s per phase; VR_BENCH_WATCHDOG=0 turns it off, any other value sets the per-phase seconds.
+    watchdog = int(os.environ.get('VR_BENCH_WATCHDOG', '900' if int(os.environ.get('WORLD_SIZE', '1')) > 1 else '0'))
+
+    def pet():
+        if watchdog > 0:
+            import faulthandler
+            faulthandler.cancel_dump_traceback_later()
+            faulthandler.dump_traceback_later(watchdog, exit=True)
+    pet()
     # stdout carries ONE JSON line and nothing else: libraries write there too (RCCL prints a version banner at its first communicator,
     # from C stdio), so file descriptor 1 points at stderr for the whole run and the line goes to the saved descriptor at the end
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    rt = Runtime(args)
+    rt = Runtime(args)                 # (builds the library on first use)
+    pet()
     wl = (StubWorkloads if rt.stub else NativeWorkloads)(rt, args)
     world, rank, T = rt.world, rt.rank, wl.T
     pmc = lambda which: '%s_%s_pmc.json' % (PROFILE_ROUND, which)        # noqa: E731
 
     def roofline(step, pmc_name):
+        pet()
         # three profiled steps, the fastest one is reported: a single serialised step is exposed to one-off stalls (seen once: a tta
         # step at 2x its usual kernel time while the timed steps of the same run were normal)
         conv_totals, rows = min((wl.profile(step) for _ in range(3)), key=lambda r: sum(x[2] for x in r[1]))
         return roofline_from_rows(rows, pmc_name, conv_totals)
 
     def run_infer(tta):
+        pet()
         step = wl.infer_step(tta)
         dt = rt.timed(step, args.steps, args.warmup)
         crops = wl.crops_tta if tta else wl.crops_plain
@@ -600,6 +608,7 @@ def main():
         return res, step
 
     def run_train(bf16=False, mfma_mode=None, configs4=False):
+        pet()
         wl.set_mode(bf16=bf16)
         if mfma_mode is not None:
             wl.set_mode(mfma_mode=mfma_mode)
@@ -652,7 +661,8 @@ def main():
         out = {
             'metric': metric, 'value': res['frames_per_sec'], 'unit': 'spectrogram-frames/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': res['ms_per_step'],
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'dtype_note': res.get('dtype', SPLIT_DTYPE),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16' if (args.bf16 or os.environ.get('VR_MFMA_MODE') == '1') else 'f32', 'dtype_note': res.get('dtype', SPLIT_DTYPE),
             'ms_per_step_per_rank': res.get('ms_per_step_per_rank'), 'allreduce_ms': res.get('allreduce_ms'),
             'data': 'synthetic (seeded noise + sines; seeded random weights, no baseline.pth exists)',
             'config': {'workload': workload, 'n_fft': N_FFT, 'hop': HOP, 'cropsize': CROP,
@@ -729,6 +739,7 @@ def main():
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
+            pet()
             out['cpu_baseline'] = wl.cpu_baseline('infer' if primary_mode in ('infer', 'tta') else 'train')
             if args.mode == 'all':
                 out['train']['cpu_baseline'] = wl.cpu_baseline('train')

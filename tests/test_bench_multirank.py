@@ -26,8 +26,11 @@ def _port():
     return p
 
 
+DETAIL = None          # set per test: the stub run's detail file goes to the test's tmp dir (a real gpurun_out/bench_detail.json stays untouched)
+
+
 def _run(cmd):
-    env = dict(os.environ, VR_BENCH_STUB='1', OMP_NUM_THREADS='1')
+    env = dict(os.environ, VR_BENCH_STUB='1', OMP_NUM_THREADS='1', VR_BENCH_DETAIL=DETAIL)
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
@@ -65,14 +68,16 @@ def _check(out, world, steps, warmup):
     roof = out['roofline']
     assert roof['classes'][0][0].startswith('conv_x3') and roof['bound'] == 'mfma' and roof['peak'] == 2500.0
     assert len(roof['classes']) <= 6 and all(len(row) == 4 for row in roof['classes'])      # [class, ms per step, bound, frac]
-    assert 'kernels' not in roof and out['detail'] == 'gpurun_out/bench_detail.json'
-    detail = json.load(open(os.path.join(ROOT, 'gpurun_out', 'bench_detail.json')))
+    assert 'kernels' not in roof and out['detail'] == DETAIL
+    detail = json.load(open(DETAIL))
     assert detail['roofline']['kernels'] and detail['roofline']['classes'][0]['class'].startswith('conv_x3')
     assert abs(roof['frac'] - 6 * 1e11 / 2500e12 / 0.5e-3) < 1e-9             # stub rows: 1e11 FLOPs in 0.5 ms on the bf16 pipe
 
 
 @pytest.mark.parametrize('world', [1, 2, 8])
-def test_bench_control_flow_under_the_drivers_launcher(world):
+def test_bench_control_flow_under_the_drivers_launcher(world, tmp_path):
+    global DETAIL
+    DETAIL = str(tmp_path / 'bench_detail.json')
     steps, warmup = 3, 1
     if world == 1:
         cmd = [sys.executable, BENCH, '--gpus', '1', '--steps', str(steps), '--warmup', str(warmup)]
@@ -82,8 +87,10 @@ def test_bench_control_flow_under_the_drivers_launcher(world):
     _check(_run(cmd), world, steps, warmup)
 
 
-def test_bench_self_launch_two_ranks():
+def test_bench_self_launch_two_ranks(tmp_path):
     """`python bench.py --gpus 2` without a launcher environment starts its own ranks (torch.distributed.run, 127.0.0.1)."""
+    global DETAIL
+    DETAIL = str(tmp_path / 'bench_detail.json')
     _check(_run([sys.executable, BENCH, '--gpus', '2', '--steps', '2', '--warmup', '1']), 2, 2, 1)
 
 

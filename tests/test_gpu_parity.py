@@ -209,6 +209,38 @@ def test_conv_x3_fused_upsample_vs_torch(vr, small, case):
     assert not np.array_equal(got[0], got[2]) and not np.array_equal(got[3], got[2])
 
 
+@pytest.mark.gpu
+def test_conv_x3_fused_upsample_never_reads_past_the_staging_tile(vr, small):
+    """the fused bilinear x2 read the +1 row / +1 column neighbours unconditionally (weight 0 at the image edge) -- up to
+    (LW + 1) * 32 + 16 bytes past the low-resolution staging tile, i.e. into the epilogue constants that follow it in LDS.  With a
+    non-finite constant there, 0 * inf = nan poisoned every output of the tile's last rows / columns.  The steps to the neighbours are
+    clamped now: an infinite bias on ONE cout must make that cout infinite and leave every other cout exactly as without it."""
+    model = small[0]
+    nat = vr.native
+    N, Cin, H, W, Cout = 1, 16, 9, 16, 32          # 18 x 32 outputs: the bottom tile rows and the right column interpolate at the image edge
+    g = torch.Generator().manual_seed(5)
+    xn = torch.randn(N, Cin, H, W, generator=g).numpy()
+    wn = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).numpy()
+    en = np.stack([np.full(Cout, 1e30, np.float32), np.full(Cout, 3e38, np.float32)], 1).copy()     # huge scale / shift in the LDS constants
+    en[:-1] = np.stack([np.ones(Cout - 1, np.float32), np.zeros(Cout - 1, np.float32)], 1)
+    outs = []
+    try:
+        model.set_option('mfma_mode', 3)
+        for poison in (False, True):
+            bn = np.zeros(Cout, np.float32)
+            if poison:
+                bn[-1] = np.inf
+            out = np.empty((N, Cout, 2 * H, 2 * W), np.float32)
+            nat.check(nat.lib().vr_debug_conv2d(model._handle.h, nat.np_ptr(xn), N, Cin, H, W, nat.np_ptr(wn), Cout, 3, 1, 1, 1, 1 | 2 | 4,
+                                                nat.np_ptr(en), ctypes.c_float(1.0), nat.np_ptr(bn), nat.np_ptr(out), None))
+            outs.append(out)
+    finally:
+        model.set_option('mfma_mode', -1)
+    assert np.isfinite(outs[0][:, :-1]).all() and np.isfinite(outs[1][:, :-1]).all()
+    assert np.array_equal(outs[0][:, :-1], outs[1][:, :-1])
+    assert np.isinf(outs[1][:, -1]).all()
+
+
 SPLIT_CASES = [(3, 64, 128, 256, 64), (3, 61, 128, 256, 64), (3, 128, 64, 256, 128)]      # big enough for the 64-cout Winograd variant
 
 

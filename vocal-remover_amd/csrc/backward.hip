@@ -484,23 +484,6 @@ void launch_avgpool_bwd(const float* gp, float* g, int N, int C, int H, int W, l
 //   wgrad: dW[o][c] = sum_{n,h,w} dz[n][o][h][w] * act(x)[n][c][h][w]   (8 channels per blockIdx.y)
 // dz is dense [N][CO][H][W].
 // ---------------------------------------------------------------------------------------------------
-template <int CO>
-__global__ __launch_bounds__(256) void thin_dgrad_kernel(Tensor x, const float* __restrict__ w, const float* __restrict__ dz,
-                                                         float* __restrict__ g, int accumulate) {
-    const long long total = (long long)x.N * x.C * x.H * x.W;
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= total) return;
-    const int wq = (int)(gid % x.W);
-    long long t = gid / x.W;
-    const int h = (int)(t % x.H); t /= x.H;
-    const int c = (int)(t % x.C);
-    const int n = (int)(t / x.C);
-    float v = 0.f;
-#pragma unroll
-    for (int o = 0; o < CO; ++o) v = fmaf(w[o * x.C + c], dz[(((long long)n * CO + o) * x.H + h) * x.W + wq], v);
-    float* q = g + (long long)n * x.sN + (long long)c * x.sC + (long long)h * x.sH + wq;
-    *q = accumulate ? *q + v : v;
-}
 
 // float4 form (round 4): one thread = four consecutive columns x 8 channels; dz is fetched once per eight channels instead of once per
 // element, the three 64-bit divisions per element are gone (the scalar form above ran at 1.2-2.4 TB/s: 445 us for the head's 2 -> 32
@@ -544,56 +527,6 @@ __global__ __launch_bounds__(256) void thin_dgrad4_kernel(Tensor x, const float*
     }
 }
 
-template <int CO>
-__global__ __launch_bounds__(256) void thin_wgrad_kernel(Tensor x, const float* __restrict__ dz, float* __restrict__ part) {
-    const int c0 = blockIdx.y * 8;
-    float acc[CO][8];
-#pragma unroll
-    for (int o = 0; o < CO; ++o)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc[o][k] = 0.f;
-    const long long total = (long long)x.N * x.H * x.W;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const int wq = (int)(e % x.W);
-        long long t = e / x.W;
-        const int h = (int)(t % x.H);
-        const int n = (int)(t / x.H);
-        float d[CO];
-#pragma unroll
-        for (int o = 0; o < CO; ++o) d[o] = dz[(((long long)n * CO + o) * x.H + h) * x.W + wq];
-        const float* aff = (h < x.hsplit) ? x.aff0 : x.aff1;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int c = c0 + k;
-            if (c < x.C) {
-                float sc = 1.f, sh = 0.f;
-                if (aff) { sc = aff[2 * c]; sh = aff[2 * c + 1]; }
-                float v = fmaf(x.p[(long long)n * x.sN + (long long)c * x.sC + (long long)h * x.sH + wq], sc, sh);
-                v = v > 0.f ? v : v * x.slope;
-                if (x.post) v *= x.post[n * x.C + c];
-#pragma unroll
-                for (int o = 0; o < CO; ++o) acc[o][k] = fmaf(d[o], v, acc[o][k]);
-            }
-        }
-    }
-    __shared__ float red[4][CO * 8];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-    for (int o = 0; o < CO; ++o)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float v = acc[o][k];
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-            if (lane == 0) red[wave][o * 8 + k] = v;
-        }
-    __syncthreads();
-    if (threadIdx.x < CO * 8) {
-        const int o = threadIdx.x / 8, k = threadIdx.x % 8;
-        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        if (c0 + k < x.C) part[(long long)blockIdx.x * CO * x.C + o * x.C + c0 + k] = v;
-    }
-}
 
 // The same with four consecutive frames per thread (16-byte loads of x and dz) and 32-bit index arithmetic: the scalar form above spends
 // its time on two 64-bit divisions and nine 4-byte loads per element (0.9 TB/s measured); rows must be 16-byte aligned.
@@ -685,7 +618,6 @@ void launch_reduce_rows(const float* part, long long stride, int P, float* out, 
 
 void launch_thin_dgrad(const Tensor& x, int CO, const float* w, const float* dz, float* g, int accumulate, hipStream_t st) {
     const long long total = (long long)x.N * x.C * x.H * x.W;
-    const unsigned grid = (unsigned)((total + 255) / 256);
     // reads x (activation derivative), dz; writes (accumulating: read-modify-writes) g
     prof_note(2.0 * CO * (double)total, 4.0 * ((accumulate ? 3.0 : 2.0) * (double)total + (double)CO * x.N * x.H * x.W));
     const bool vec = (x.W & 3) == 0 && (x.sH & 3) == 0 && (x.sC & 3) == 0 && (x.sN & 3) == 0 &&
@@ -695,8 +627,11 @@ void launch_thin_dgrad(const Tensor& x, int CO, const float* w, const float* dz,
         const dim3 g4((unsigned)(((long long)x.N * x.H * (x.W >> 2) + 255) / 256), (unsigned)((x.C + 7) / 8));
         if (CO == 1) VR_LAUNCH((thin_dgrad4_kernel<1>), g4, dim3(256), 0, st, x, w, dz, g, accumulate);
         else VR_LAUNCH((thin_dgrad4_kernel<2>), g4, dim3(256), 0, st, x, w, dz, g, accumulate);
-    } else if (CO == 1) VR_LAUNCH((thin_dgrad_kernel<1>), dim3(grid), dim3(256), 0, st, x, w, dz, g, accumulate);
-    else VR_LAUNCH((thin_dgrad_kernel<2>), dim3(grid), dim3(256), 0, st, x, w, dz, g, accumulate);
+    } else {
+        // (round 6: the scalar per-element form is gone -- frames % 16 == 0 (lib/nets.py:129 / spec_utils.crop_center) makes every width
+        // the model can produce a multiple of 4, and nothing ever reached it)
+        throw Error(-2, "thin conv data gradient: widths and strides must be multiples of 4 floats");
+    }
     VR_HIP(hipGetLastError());
 }
 
@@ -717,8 +652,9 @@ void launch_thin_wgrad(const Tensor& x, int CO, const float* dz, float* part, fl
     if (vec) {
         if (CO == 1) VR_LAUNCH((thin_wgrad4_kernel<1>), grid, dim3(256), 0, st, x, dz, part);
         else VR_LAUNCH((thin_wgrad4_kernel<2>), grid, dim3(256), 0, st, x, dz, part);
-    } else if (CO == 1) VR_LAUNCH((thin_wgrad_kernel<1>), grid, dim3(256), 0, st, x, dz, part);
-    else VR_LAUNCH((thin_wgrad_kernel<2>), grid, dim3(256), 0, st, x, dz, part);
+    } else {
+        throw Error(-2, "thin conv weight gradient: widths and strides must be multiples of 4 floats");
+    }
     VR_HIP(hipGetLastError());
     launch_reduce_rows(part, (long long)CO * x.C, nb, dw, (long long)CO * x.C, accumulate, 1.f, st);
 }

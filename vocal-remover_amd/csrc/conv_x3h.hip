@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, (X3hCfg<MT, TH>::OCC + (HI ? 1 : 0))) void con
     const ConvSrc& us = a.src[0].up ? a.src[0] : (a.src[1].up ? a.src[1] : a.src[2]);
     constexpr bool any_up = UP;
     int lrow = 0, lcol4 = 0;                       // low-res pixel this thread fetches (byte column; 2^31: none)
-    int lidx[NPASS];
+    int lidx[NPASS], lstep[NPASS];                 // (lstep: byte step to the +1 row << 16 | to the +1 column; 0 where that neighbour's weight is exactly 0)
     float lh[NPASS], lw_[NPASS];
     if (any_up) {
         const int lr0 = (int)(us.rh * (float)(h0 > 0 ? h0 - 1 : 0)), lc0 = (int)(us.rw * (float)(w0 > 0 ? w0 - 1 : 0));
@@ -155,6 +155,12 @@ __global__ __launch_bounds__(256, (X3hCfg<MT, TH>::OCC + (HI ? 1 : 0))) void con
             const float h1r = us.rh * (float)(ok ? hi : 0), w1r = us.rw * (float)(ok ? wi : 0);
             const int h1 = (int)h1r, w1 = (int)w1r;
             lidx[p] = ok ? ((h1 - lr0) * Cfg::LW + (w1 - lc0)) * 32 : -1;        // byte offset of the pixel's 8 channels in the staging tile
+            // A pixel on the last low-resolution row / column has weight exactly 0 on its +1 neighbour, which would lie OUTSIDE the staging
+            // tile (up to (LW + 1) * 32 + 16 bytes past it -- epilogue constants, wave maxima or beyond LDS_BYTES; 0 * inf or
+            // 0 * nan would poison the sum).  Step 0 there: the neighbour read lands on the pixel itself.
+            const int rs = (h1 + 1 < us.H && h1 + 1 - lr0 < Cfg::LROWS) ? Cfg::LW * 32 : 0;
+            const int cs = (w1 + 1 < us.W && w1 + 1 - lc0 < Cfg::LW) ? 32 : 0;
+            lstep[p] = (rs << 16) | cs;
             lh[p] = h1r - (float)h1;
             lw_[p] = w1r - (float)w1;
         }
@@ -279,9 +285,10 @@ __global__ __launch_bounds__(256, (X3hCfg<MT, TH>::OCC + (HI ? 1 : 0))) void con
             if ((p + 1) * 256 <= NSLOT || s < NSLOT) {
                 vr_i32x4 ph, pl;
                 if (upm[PAR] != 0u) {
-                    // torch's bilinear, align_corners=True (pointwise.hip: upsample2x_kernel): the +1 neighbours are read even at the
-                    // last row / column, where their weight is exactly 0 and the staging tile holds zeros
+                    // torch's bilinear, align_corners=True (pointwise.hip: upsample2x_kernel); the steps to the +1 neighbours are clamped
+                    // (lstep) so that nothing outside the staging tile is ever read
                     const char* lq = smem_x3h + Cfg::L_OFF + (lidx[p] >= 0 ? lidx[p] : 0);
+                    const int rs = lstep[p] >> 16, cs = lstep[p] & 0xffff;
                     const float h1l = lh[p], h0l = 1.f - h1l, w1l = lw_[p], w0l = 1.f - w1l;
                     if (upm[PAR] == 0xFFu) {
                         // the whole chunk is upsampled (64 of the 65 upsampled channels of a dec1 layer): eight 16-byte reads up front,
@@ -291,7 +298,7 @@ __global__ __launch_bounds__(256, (X3hCfg<MT, TH>::OCC + (HI ? 1 : 0))) void con
                         for (int q4 = 0; q4 < 4; ++q4)
 #pragma unroll
                             for (int hf = 0; hf < 2; ++hf)
-                                nb[q4][hf] = *reinterpret_cast<const vr_f32x4h*>(lq + ((q4 >> 1) * Cfg::LW + (q4 & 1)) * 32 + hf * 16);
+                                nb[q4][hf] = *reinterpret_cast<const vr_f32x4h*>(lq + (q4 >> 1) * rs + (q4 & 1) * cs + hf * 16);
 #pragma unroll
                         for (int cl = 0; cl < 8; ++cl) {
                             const float v00 = nb[0][cl >> 2][cl & 3], v01 = nb[1][cl >> 2][cl & 3], v10 = nb[2][cl >> 2][cl & 3], v11 = nb[3][cl >> 2][cl & 3];
@@ -302,8 +309,9 @@ __global__ __launch_bounds__(256, (X3hCfg<MT, TH>::OCC + (HI ? 1 : 0))) void con
 #pragma unroll
                         for (int cl = 0; cl < 8; ++cl) {
                             if ((upm[PAR] >> cl) & 1u) {
-                                const float* q = reinterpret_cast<const float*>(lq) + cl;
-                                const float v00 = q[0], v01 = q[8], v10 = q[Cfg::LW * 8], v11 = q[Cfg::LW * 8 + 8];
+                                const char* q = lq + cl * 4;
+                                const float v00 = *reinterpret_cast<const float*>(q), v01 = *reinterpret_cast<const float*>(q + cs),
+                                            v10 = *reinterpret_cast<const float*>(q + rs), v11 = *reinterpret_cast<const float*>(q + rs + cs);
                                 const float v = h0l * (w0l * v00 + w1l * v01) + h1l * (w0l * v10 + w1l * v11);
                                 xr[PAR][p][cl] = lidx[p] >= 0 ? v : 0.f;
                             }

@@ -151,7 +151,6 @@ void launch_istft_masked(const FFTPlan& pl, const float2* spec, int hop, int T, 
 // per-row partial maxima into stats (16 B header + 2 x bins rows of (max |X| bits, 64-bit lexicographic complex key))
 void launch_mag_pad(const float2* spec, int bins, int T, float* mag_pad, int Wpad, int pad_l,
                     unsigned* stats, hipStream_t st);
-void launch_stats_init(unsigned* stats, hipStream_t st);
 // aff[0..3] = (1/coef, 0, 1/coef, 0), coef = max|X| (mode 0) or |lexicographic max| (mode 1)
 void launch_coef_affine(const unsigned* stats, int rows, int mode, float* aff, hipStream_t st);   // rows = 2 * bins partials
 // y = m*X, v = (1-m)*X with m = mask_a[.., t] (tta=0) or 0.5*(mask_a[.., t] + mask_b[.., t + shift])

@@ -355,6 +355,15 @@ void Model::set_option(const std::string& name, int value) {
         mfma_mode = value < 0 ? default_mfma_mode : value; affine_dirty = true;   // (the next eval forward refreshes the derived weight copies)
     }
     else if (name == "adam_reset") reset_adam_state();      // a freshly constructed torch.optim.Adam has no moments
+    else if (name == "hip_graph" || name == "conv_x3p" || name == "wgrad_x3h" || name == "conv_x3b") {
+        // options of round 4 whose kernels moved to tools/experiments in round 5: accepted and ignored, so that an older caller keeps
+        // working; said once per option name
+        static std::string told;
+        if (told.find("|" + name + "|") == std::string::npos) {
+            told += "|" + name + "|";
+            fprintf(stderr, "libvr_mi355: option '%s' was retired with its kernel (tools/experiments/README.md); ignored\n", name.c_str());
+        }
+    }
     else throw Error(-2, "unknown option: " + name);
 }
 

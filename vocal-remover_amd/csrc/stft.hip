@@ -350,17 +350,6 @@ __device__ __forceinline__ float unord32(unsigned o) {
     return __uint_as_float(u);
 }
 
-__global__ void stats_init_kernel(unsigned* stats) {
-    stats[0] = 0u;                                      // max |X| bits (>= 0)
-    stats[1] = 0u;
-    // lexicographic max starts at 0+0j: the zero padding is part of the array the reference reduces
-    unsigned long long key = ((unsigned long long)ord32(0.f) << 32) | ord32(0.f);
-    *reinterpret_cast<unsigned long long*>(stats + 2) = key;
-}
-void launch_stats_init(unsigned* stats, hipStream_t st) {
-    VR_LAUNCH(stats_init_kernel, dim3(1), dim3(1), 0, st, stats);
-    VR_HIP(hipGetLastError());
-}
 
 // One workgroup per (channel, bin) row: |X| into the padded crop source (row-contiguous loads and stores, no 64-bit
 // division per element) and the row's two maxima into part[row] -- no atomics; coef_affine_kernel reduces the 2 x bins
