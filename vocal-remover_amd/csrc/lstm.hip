@@ -64,61 +64,83 @@ __global__ void bilstm_kernel(const float* __restrict__ gx, const float* __restr
     }
 }
 
-// Register-resident form for H <= 64 (the shipped nets: nout_lstm = 128 -> H = 64): thread g keeps ITS row of
-// W_hh (H floats) in registers, h_{t-1} is broadcast from LDS with 16-byte reads, four independent FMA chains.
-// The LDS form above spends ~1.4 us per step on 2*H dependent LDS reads; this one ~0.2 us.
+// Register-resident quad form for H in {16, 32, 64} (the shipped nets: nout_lstm = 128 -> H = 64), round 6: thread 4 u + q keeps row
+// q * H + u of W_hh (H floats) in registers, h_{t-1} is broadcast from LDS with 16-byte reads, four independent FMA chains.  The four gates
+// of a hidden unit sit in four ADJACENT LANES of one wave, so the cell update needs no LDS round trip and no barrier between the
+// matrix-vector product and the gates -- four DPP quad broadcasts instead.  One barrier per step (h is double-buffered in LDS), every lane
+// evaluates ONE transcendental for its gate (sigmoid(x) = 0.5 + 0.5 tanh(x / 2): one instruction stream for all four gates, per-lane
+// constants), and h / the projections move to and from HBM four time steps at a time.  0.5 us per step; its predecessor (rounds 2-5: thread
+// g = gate row g, two barriers, gate pre-activations through LDS, five libm transcendentals on one wave while three idled) took 0.9 us,
+// the LDS form above 1.4 us.  S30 inference: 0.54 -> 0.28 ms of kernel time per step (gpurun_out r6call6; wall time unchanged -- the
+// recurrence runs beside the x2 upsample on the side stream).
+__device__ __forceinline__ float tanh_fast(float x) {
+    // 1 - 2 / (1 + e^(2x)): v_exp_f32 + v_rcp_f32; saturates to +-1 through inf / 0, absolute error ~1e-7
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + e);
+}
 template <int H>
-__global__ __launch_bounds__(4 * H) void bilstm_reg_kernel(const float* __restrict__ gx, const float* __restrict__ whh_f,
-                                                           const float* __restrict__ whh_r, float* __restrict__ out,
-                                                           float* __restrict__ save, int T) {
+__global__ __launch_bounds__(4 * H) void bilstm_quad_kernel(const float* __restrict__ gx, const float* __restrict__ whh_f,
+                                                            const float* __restrict__ whh_r, float* __restrict__ out,
+                                                            float* __restrict__ save, int T) {
     constexpr int G = 4 * H;
-    __shared__ __attribute__((aligned(16))) float hbuf[H];
-    __shared__ float abuf[G];
+    __shared__ __attribute__((aligned(16))) float hbuf[2][H];
     const int n = blockIdx.x, dir = blockIdx.y;
-    const int g = threadIdx.x;
-    const float* whh = (dir ? whh_r : whh_f) + (long long)g * H;
+    const int tid = threadIdx.x;
+    const int u = tid >> 2, q = tid & 3;                         // hidden unit, gate (0 i, 1 f, 2 g, 3 o): row q * H + u of W_hh
+    const int row = q * H + u;
+    const float* whh = (dir ? whh_r : whh_f) + (long long)row * H;
     float w[H];
 #pragma unroll
     for (int k = 0; k < H; k += 4) {
         const float4 v = *reinterpret_cast<const float4*>(whh + k);
         w[k] = v.x; w[k + 1] = v.y; w[k + 2] = v.z; w[k + 3] = v.w;
     }
-    if (g < H) hbuf[g] = 0.f;
+    const float sc = q == 2 ? 1.f : 0.5f, mul = q == 2 ? 1.f : 0.5f, add = q == 2 ? 0.f : 0.5f;
+    if (tid < H) { hbuf[0][tid] = 0.f; hbuf[1][tid] = 0.f; }
     float c = 0.f;
-    const float* gxp = gx + ((long long)n * 2 * G + (long long)dir * G + g) * T;
-    float* outp = out + ((long long)n * 2 * H + (long long)dir * H + g) * T;
+    const float* gxp = gx + ((long long)n * 2 * G + (long long)dir * G + row) * T;
+    float* outp = out + ((long long)n * 2 * H + (long long)dir * H + u) * T;
     __syncthreads();
-    float pre = gxp[dir ? T - 1 : 0];
-    for (int step = 0; step < T; ++step) {
-        const int t = dir ? T - 1 - step : step;
-        float nxt = 0.f;
-        if (step + 1 < T) nxt = gxp[dir ? t - 1 : t + 1];           // prefetch next step's projection
-        float a0 = pre, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    // time runs in blocks of four steps: block b covers t = 4 b .. 4 b + 3 (forward) resp. the mirrored block in descending order
+    const int nb = T >> 2;                                       // (launch_bilstm_train takes this kernel only when T % 4 == 0)
+    float4 pre = *reinterpret_cast<const float4*>(gxp + (dir ? T - 4 : 0));
+    int cur = 0;
+    for (int b = 0; b < nb; ++b) {
+        const int t0 = dir ? T - 4 - 4 * b : 4 * b;
+        float4 nxt = pre;
+        if (b + 1 < nb) nxt = *reinterpret_cast<const float4*>(gxp + (dir ? t0 - 4 : t0 + 4));      // the next block's projections
+        float hq[4];
 #pragma unroll
-        for (int k = 0; k < H; k += 4) {
-            const float4 h4 = *reinterpret_cast<const float4*>(hbuf + k);      // same address in every lane: broadcast
-            a0 = fmaf(w[k], h4.x, a0);
-            a1 = fmaf(w[k + 1], h4.y, a1);
-            a2 = fmaf(w[k + 2], h4.z, a2);
-            a3 = fmaf(w[k + 3], h4.w, a3);
-        }
-        abuf[g] = (a0 + a1) + (a2 + a3);
-        __syncthreads();
-        if (g < H) {
-            const float ig = sigmoidf_(abuf[g]);
-            const float fg = sigmoidf_(abuf[H + g]);
-            const float gg = tanhf(abuf[2 * H + g]);
-            const float og = sigmoidf_(abuf[3 * H + g]);
-            c = fg * c + ig * gg;
-            const float h = og * tanhf(c);
-            hbuf[g] = h;
-            outp[t] = h;
-            if (save) {
-                float* sv = save + (((long long)n * 2 + dir) * T + t) * 5 * H + g;
-                sv[0] = ig; sv[H] = fg; sv[2 * H] = gg; sv[3 * H] = og; sv[4 * H] = c;
+        for (int s = 0; s < 4; ++s) {
+            const int j = dir ? 3 - s : s;                       // position inside the block, in processing order
+            float a0 = j == 0 ? pre.x : (j == 1 ? pre.y : (j == 2 ? pre.z : pre.w)), a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int k = 0; k < H; k += 4) {
+                const float4 h4 = *reinterpret_cast<const float4*>(&hbuf[cur][k]);       // same address in every lane: broadcast
+                a0 = fmaf(w[k], h4.x, a0);
+                a1 = fmaf(w[k + 1], h4.y, a1);
+                a2 = fmaf(w[k + 2], h4.z, a2);
+                a3 = fmaf(w[k + 3], h4.w, a3);
             }
+            const float act = fmaf(tanh_fast(((a0 + a1) + (a2 + a3)) * sc), mul, add);     // sigmoid for i, f, o; tanh for g
+            const int ai = __float_as_int(act);
+            const float ig = __int_as_float(__builtin_amdgcn_update_dpp(0, ai, 0x00, 0xF, 0xF, true));     // quad_perm [0,0,0,0]
+            const float fg = __int_as_float(__builtin_amdgcn_update_dpp(0, ai, 0x55, 0xF, 0xF, true));     // [1,1,1,1]
+            const float gg = __int_as_float(__builtin_amdgcn_update_dpp(0, ai, 0xAA, 0xF, 0xF, true));     // [2,2,2,2]
+            const float og = __int_as_float(__builtin_amdgcn_update_dpp(0, ai, 0xFF, 0xF, 0xF, true));     // [3,3,3,3]
+            c = fmaf(fg, c, ig * gg);                            // (all four lanes of the quad carry the unit's cell state)
+            const float h = og * tanh_fast(c);
+            hq[j] = h;
+            if (q == 0) hbuf[cur ^ 1][u] = h;
+            if (save) {                                          // [n][dir][t][5H]: (i, f, g, o, c) per step, for the backward pass
+                float* sv = save + (((long long)n * 2 + dir) * T + (t0 + j)) * 5 * H;
+                sv[row] = act;
+                if (q == 0) sv[4 * H + u] = c;
+            }
+            __syncthreads();
+            cur ^= 1;
         }
-        __syncthreads();
+        if (q == 0) *reinterpret_cast<float4*>(outp + t0) = make_float4(hq[0], hq[1], hq[2], hq[3]);
         pre = nxt;
     }
 }
@@ -126,10 +148,12 @@ __global__ __launch_bounds__(4 * H) void bilstm_reg_kernel(const float* __restri
 void launch_bilstm_train(const float* gx, const float* whh_f, const float* whh_r, float* out, float* save,
                          int N, int T, int H, hipStream_t st) {
     static const bool reg_form = !getenv("VR_LSTM_LDS");
-    if (reg_form && (H == 64 || H == 32 || H == 16)) {
-        if (H == 64) VR_LAUNCH(bilstm_reg_kernel<64>, dim3(N, 2), dim3(256), 0, st, gx, whh_f, whh_r, out, save, T);
-        else if (H == 32) VR_LAUNCH(bilstm_reg_kernel<32>, dim3(N, 2), dim3(128), 0, st, gx, whh_f, whh_r, out, save, T);
-        else VR_LAUNCH(bilstm_reg_kernel<16>, dim3(N, 2), dim3(64), 0, st, gx, whh_f, whh_r, out, save, T);
+    // (T = frames / 2 with frames % 16 == 0, workspace buffers are 256-byte aligned: the shipped nets always take this branch)
+    if (reg_form && (H == 64 || H == 32 || H == 16) && (T & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(gx) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        if (H == 64) VR_LAUNCH(bilstm_quad_kernel<64>, dim3(N, 2), dim3(256), 0, st, gx, whh_f, whh_r, out, save, T);
+        else if (H == 32) VR_LAUNCH(bilstm_quad_kernel<32>, dim3(N, 2), dim3(128), 0, st, gx, whh_f, whh_r, out, save, T);
+        else VR_LAUNCH(bilstm_quad_kernel<16>, dim3(N, 2), dim3(64), 0, st, gx, whh_f, whh_r, out, save, T);
         VR_HIP(hipGetLastError());
         return;
     }
