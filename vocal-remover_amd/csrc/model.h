@@ -207,6 +207,11 @@ private:
     char* x3_arena = nullptr;                            // mfma_mode 2: bf16-plane copies of the direct 3x3 stride-1 weights (conv_x3.hip)
     char* x3t_arena = nullptr;                           //              and of their flipped / transposed forms (data gradient)
     std::map<const Param*, void*> x3t_of;
+    // deferred weight-gradient slab sums of one backward pass (launch_wgrad_reduce_batched, round 6)
+    std::vector<WgReduceDesc> wred_host, wred_sent;
+    WgReduceDesc* wred_dev = nullptr;
+    size_t wred_cap = 0;
+    void flush_wgrad_sums();
     struct X3Batch { std::vector<X3WDesc> host; X3WDesc* dev = nullptr; long long max_elems = 0; };
     X3Batch xb_fwd, xb_bwd;
     void run_x3_batch(X3Batch& b, std::vector<X3WDesc>& descs);

@@ -246,7 +246,7 @@ Model::~Model() {
     hipFree(wire_buf);
     if (stream) hipStreamSynchronize(stream);
     hipFree(p_arena); hipFree(b_arena); hipFree(d_fold);
-    hipFree(ws.base); hipFree(io.base); hipFree(gs.base); hipFree(wino_arena); hipFree(winot_arena); hipFree(wino6_arena); hipFree(winot6_arena); hipFree(x3_arena); hipFree(x3t_arena); hipFree(xb_fwd.dev); hipFree(xb_bwd.dev); hipFree(wb_fwd.dev); hipFree(wb_bwd.dev); hipFree(wb_fwd6.dev); hipFree(wb_bwd6.dev); hipFree(aug_buf);
+    hipFree(ws.base); hipFree(io.base); hipFree(gs.base); hipFree(wino_arena); hipFree(winot_arena); hipFree(wino6_arena); hipFree(winot6_arena); hipFree(x3_arena); hipFree(x3t_arena); hipFree(xb_fwd.dev); hipFree(xb_bwd.dev); hipFree(wb_fwd.dev); hipFree(wb_bwd.dev); hipFree(wb_fwd6.dev); hipFree(wb_bwd6.dev); hipFree(aug_buf); hipFree(wred_dev);
     for (BaseNetL& B : nets_) hipFree(B.lstm.bias_sum);
     hipFree(g_arena); hipFree(m_arena); hipFree(v_arena); hipFree(wt_arena); hipFree(d_flip); hipFree(dropout_buf);
     hipFree(plan.twiddle); hipFree(plan.window);
@@ -1416,15 +1416,23 @@ void Model::separate_api(const float* spec, bool on_dev, int T, int tta, int bat
                 VR_HIP(hipMalloc(reinterpret_cast<void**>(&l.ws.base), ws.cap));
                 l.ws.cap = ws.cap;
             }
-            const int per = (nb + K - 1) / K;
+            // The host enqueues part 0 completely before part 1 (~0.5 ms of launches: profiles/README.md), so the later lanes start late:
+            // VR_LANE0_EXTRA = n gives part 0 n crops more than an even share.  Measured in round 6 (tools/gpu_r6_call7.sh, S30, two lanes):
+            // 6 + 5 crops 8.63 - 8.78 ms, 7 + 4 8.69 - 8.73, 8 + 3 8.90; three lanes 10.4, one lane 9.24 -- the even split stays.
+            static const int extra_env = getenv("VR_LANE0_EXTRA") ? atoi(getenv("VR_LANE0_EXTRA")) : -1;
+            const int even = (nb + K - 1) / K;
+            int head = extra_env >= 0 ? extra_env : 0;
+            if (even + head > nb - (K - 1)) head = std::max(0, nb - (K - 1) - even);      // every part keeps at least one crop
+            const int per0 = even + head;
+            const int per = K > 1 ? (nb - per0 + K - 2) / (K - 1) : nb;
             for (int j = 1; j < K; ++j) {                    // `mag` is ready at this point of the main stream
                 hipEvent_t es = lanes[j - 1].start;
                 VR_HIP(hipEventRecord(es, stream));
                 VR_HIP(hipStreamWaitEvent(lanes[j - 1].main, es, 0));
             }
-            run_crops(i, std::min(per, nb));
+            run_crops(i, std::min(per0, nb));
             for (int j = 1; j < K; ++j) {
-                const int first = j * per, count = std::min(per, nb - first);
+                const int first = per0 + (j - 1) * per, count = std::min(per, nb - first);
                 if (count <= 0) break;
                 swap_lane(j - 1);
                 try { run_crops(i + first, count); } catch (...) { swap_lane(j - 1); throw; }

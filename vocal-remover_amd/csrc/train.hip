@@ -319,6 +319,12 @@ void Model::backward() {
             hipStreamWaitEvent(m->stream, m->ev_join, 0);
         }
     } join{this};
+    // The 107 wgrad_reduce launches of a step (~10 us each, launch-bound) become ONE launch behind the last weight gradient: launch_wgrad
+    // only records what it would have summed (vr_common.h); flush_wgrad_sums() at the end of the tape launches the sum.
+    static const bool defer_on = !getenv("VR_NO_WGRAD_DEFER");
+    struct Unsink { ~Unsink() { wgrad_defer_to(nullptr); } } unsink;      // (also when a launch throws)
+    wred_host.clear();
+    if (defer_on && !dry) wgrad_defer_to(&wred_host);
     // Stages 1-2: the high-band records (chain 1) are independent of the low-band ones; in the reversed tape
     // they come first after stage 3, so they are enqueued on a second stream and the low chain follows on the main one.
     static const bool bwd_fork = !getenv("VR_NO_BWD_FORK");
@@ -390,6 +396,31 @@ void Model::backward() {
             break;
         }
     }
+    wgrad_defer_to(nullptr);
+    flush_wgrad_sums();
+}
+
+// ONE launch for every deferred weight-gradient slab sum of this backward pass, behind the last weight gradient on its stream
+void Model::flush_wgrad_sums() {
+    if (wred_host.empty()) return;
+    long long blocks = 0;
+    for (WgReduceDesc& d : wred_host) { d.blk0 = blocks; blocks += (d.n + 63) / 64; }
+    const size_t bytes = wred_host.size() * sizeof(WgReduceDesc);
+    hipStream_t st = wgrad_on_side ? side_stream : stream;
+    if (wred_cap < wred_host.size()) {
+        if (wred_dev) { VR_HIP(hipDeviceSynchronize()); hipFree(wred_dev); }
+        wred_dev = nullptr; wred_cap = 0; wred_sent.clear();
+        VR_HIP(hipMalloc(reinterpret_cast<void**>(&wred_dev), 2 * bytes));
+        wred_cap = 2 * wred_host.size();
+    }
+    // the table is the same in every step of a plan (bump-allocated slabs, fixed gradient arena): uploaded only when it changed
+    if (wred_sent.size() != wred_host.size() || memcmp(wred_sent.data(), wred_host.data(), bytes) != 0) {
+        VR_HIP(hipStreamSynchronize(st));                         // (the previous step's launch may still be reading the old table)
+        VR_HIP(hipMemcpy(wred_dev, wred_host.data(), bytes, hipMemcpyHostToDevice));
+        wred_sent = wred_host;
+    }
+    launch_wgrad_reduce_batched(wred_dev, (int)wred_host.size(), blocks, st);
+    wred_host.clear();
 }
 
 void Model::train_fwd_bwd_api(const float* X, const float* Y, bool on_dev, int B, int T, int accumulation_steps,

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 namespace vr {
 
@@ -187,6 +188,12 @@ struct WgradArgs {
     int allow_wino;            // 1: 3x3 stride-1 layers with plain inputs may take the Winograd F(3x3,2x2) kernel (wgrad_wino.hip)
 };
 double launch_wgrad(const WgradArgs& a, const ConvShape& s, float* grad_out, int accumulate, hipStream_t st);
+// Deferred slab sums (round 6): while a sink is set (thread-local), launch_wgrad records WHAT its wgrad_reduce launch would have summed
+// instead of launching it -- 107 launches of ~10 us per train step -- and Model::backward() sums all of them in ONE launch at the end
+// (the slabs live in the step's bump-allocated workspace until the next step).
+struct WgReduceDesc { const float* part; long long stride; float* out; long long n; int P; int accumulate; long long blk0; };
+void wgrad_defer_to(std::vector<WgReduceDesc>* sink);          // nullptr: launch_wgrad sums immediately again
+void launch_wgrad_reduce_batched(const WgReduceDesc* d_descs, int n, long long total_blocks, hipStream_t st);
 size_t wgrad_scratch_floats(const WgradArgs& a, const ConvShape& s);
 
 // Returns the algorithmic FLOPs of the launch (2*MACs) for roofline accounting.

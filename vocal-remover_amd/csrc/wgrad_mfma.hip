@@ -505,8 +505,58 @@ static void wg_launch_ws(const WgradArgs& a, int MB, hipStream_t st) {
     else wg_launch_ws_inst<KS, S, TH, TW, 1>(a, st);
 }
 
+// the same sum for MANY layers in one launch: block b belongs to the descriptor d with d.blk0 <= b < next.blk0 (binary search over <= 128)
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const WgReduceDesc* __restrict__ descs, int nd) {
+    __shared__ float red[4][64];
+    int lo = 0, hi = nd - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].blk0 <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const WgReduceDesc d = descs[lo];
+    const float* __restrict__ part = d.part;
+    const long long stride = d.stride;
+    const int P = d.P;
+    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const long long i = ((long long)blockIdx.x - d.blk0) * 64 + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < d.n) {
+        int p = q;
+        for (; p + 12 < P; p += 16) {
+            s0 += part[(long long)p * stride + i];
+            s1 += part[(long long)(p + 4) * stride + i];
+            s2 += part[(long long)(p + 8) * stride + i];
+            s3 += part[(long long)(p + 12) * stride + i];
+        }
+        for (; p < P; p += 4) s0 += part[(long long)p * stride + i];
+    }
+    red[q][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (q == 0 && i < d.n) {
+        const float s = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);        // (the order of wgrad_reduce_kernel: bit-equal results)
+        d.out[i] = d.accumulate ? d.out[i] + s : s;
+    }
+}
+void launch_wgrad_reduce_batched(const WgReduceDesc* d_descs, int n, long long total_blocks, hipStream_t st) {
+    if (n <= 0) return;
+    VR_LAUNCH(wgrad_reduce_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, d_descs, n);
+    VR_HIP(hipGetLastError());
+}
+
+static thread_local std::vector<WgReduceDesc>* g_wgrad_sink = nullptr;
+void wgrad_defer_to(std::vector<WgReduceDesc>* sink) { g_wgrad_sink = sink; }
+
 static void wgrad_reduce(const WgradArgs& a, float* grad_out, int accumulate, hipStream_t st) {
     const long long n = a.part_stride;
+    if (g_wgrad_sink) {
+        // a later layer of the same step may add into the same gradient (shared weights do not exist in this net, but the debug hooks
+        // accumulate on purpose): two deferred sums into one `out` would race inside the batched launch -- the second one runs now
+        for (const WgReduceDesc& d : *g_wgrad_sink)
+            if (d.out == grad_out) goto immediate;
+        g_wgrad_sink->push_back(WgReduceDesc{a.part, a.part_stride, grad_out, n, a.P, accumulate, 0});
+        return;
+    }
+immediate:
     VR_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, a.part, a.part_stride,
                        a.P, grad_out, n, accumulate);
     VR_HIP(hipGetLastError());
