@@ -57,7 +57,7 @@ import __graft_entry__  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense bf16 matrix peak (never the 2:1-sparsity figure)
 HBM_PEAK_TBS = 8.0
-PROFILE_ROUND = 'r05'              # profiles/<round>_{infer,tta,train}_pmc.json: the PMC passes `traffic` is read from
+PROFILE_ROUND = 'r06'              # profiles/<round>_{infer,tta,train}_pmc.json: the PMC passes `traffic` is read from
 
 # kernel name -> (class label, matrix pipe or None).  Everything not listed is priced against HBM when the library noted algorithmic
 # bytes for it, and reported as 'other' (latency / launch bound: LSTM recurrence, finalize kernels, descriptor refreshes) when not.

@@ -156,6 +156,11 @@ def test_every_kernel_of_the_library_is_reached_by_a_documented_shape_or_option(
         col.run('vr_debug_conv2d, mfma_mode %d' % mode, h, lambda: nat.check(nat.lib().vr_debug_conv2d(
             h.h, nat.np_ptr(xn), 1, 16, 16, 32, nat.np_ptr(wn), 32, 3, 1, 1, 1, 2, None, ctypes.c_float(1.0), None, nat.np_ptr(out), None)))
     small.set_option('mfma_mode', -1)
+    # the single-layer backward hook sums its weight-gradient slabs at once (wgrad_reduce_kernel); Model::backward defers them into one launch
+    dzn = np.random.default_rng(5).standard_normal((1, 32, 16, 32)).astype(np.float32)
+    dxo, dwo = np.empty_like(xn), np.empty_like(wn)
+    col.run('vr_debug_conv2d_backward', h, lambda: nat.check(nat.lib().vr_debug_conv2d_backward(
+        h.h, nat.np_ptr(xn), 1, 16, 16, 32, nat.np_ptr(wn), 32, 3, 1, 1, 1, 0, None, ctypes.c_float(1.0), nat.np_ptr(dzn), nat.np_ptr(dxo), nat.np_ptr(dwo))))
     # a source that arrives with a PENDING BatchNorm affine + LeakyReLU (the model itself materialises those; the hook hands them through):
     # the warp-specialised fused-loader kernel of round 1 (conv_ws.hip) on a grid of >= 128 tiles
     xa = np.random.default_rng(4).standard_normal((4, 16, 128, 64)).astype(np.float32)
