@@ -64,6 +64,7 @@ PROFILE_ROUND = 'r06'              # profiles/<round>_{infer,tta,train}_pmc.json
 KERNEL_CLASSES = (
     ('conv_x3_kernel', 'conv_x3: 3x3 stride-1 forward + data gradient, fp32 products from six bf16 products', 'bf16'),
     ('conv_x3h_kernel', 'conv_x3h: 3x3 stride-1 forward + data gradient, fp32-grade products from three fp16 products (mfma_mode 3)', 'f16x3'),
+    ('conv_x3d_', 'conv_x3d: 16-column layers (ASPP dilated 3x3 + 1x1 branches in one launch, enc5.conv2), forward + data gradient, three fp16 products (mfma_mode 3)', 'f16x3'),
     ('wgrad_wino_', 'wgrad_wino: 3x3 stride-1 weight gradient, Winograd F(3x3,2x2), fp32 MFMA', 'fp32'),
     ('conv_wino_kernel', 'conv_wino: 3x3 stride-1, Winograd F(2x2,3x3), fp32 MFMA (mfma_mode 0)', 'fp32'),
     ('conv_dma_kernel<1,', 'conv 1x1 (ASPP, tails, LSTM projection / dense), fp32 MFMA', 'fp32'),

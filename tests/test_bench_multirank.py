@@ -131,8 +131,8 @@ def test_every_conv_and_wgrad_kernel_of_the_library_has_a_matrix_pipe_class():
     out = subprocess.run([nm, '-C', __graft_entry__.LIB], capture_output=True, text=True).stdout
     names = sorted({ln.split('__device_stub__', 1)[1].split('(')[0] for ln in out.splitlines() if '__device_stub__' in ln})
     assert len(names) > 100, len(names)
-    # (wgrad_reduce_kernel sums partial slabs: a streaming kernel, not a multiply)
-    mac = [n for n in names if n.startswith(('conv_', 'wgrad_')) and 'weights' not in n and n != 'wgrad_reduce_kernel']
+    # (wgrad_reduce_kernel / wgrad_reduce_batched_kernel sum partial slabs: streaming kernels, not multiplies)
+    mac = [n for n in names if n.startswith(('conv_', 'wgrad_')) and 'weights' not in n and not n.startswith('wgrad_reduce')]
     assert any(n.startswith('conv_x3h_kernel') for n in mac) and any(n.startswith('wgrad_wino_r_kernel') for n in mac)
     missing = [n for n in mac if bench.classify('vr::' + n)[1] not in ('bf16', 'f16x3', 'f16w', 'fp32')]
     assert not missing, missing

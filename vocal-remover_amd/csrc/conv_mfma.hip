@@ -343,6 +343,8 @@ void conv_fill_tiling(ConvArgs& a, const ConvShape& s) {
     if (thin16_pick(a, s, &thin_th)) { thin16_fill_tiling(a, thin_th); return; }
     X3Tile x3t;
     if (x3_pick(a, s, &x3t)) { x3_fill_tiling(a, x3t); return; }
+    int x3d_mt;
+    if (x3d_pick(a, s, &x3d_mt)) { x3d_fill_tiling(a, x3d_mt); return; }
     if (wino_pick(a, s, &wino_mt)) { wino_fill_tiling(a, wino_mt); return; }
     DmaTile dt;
     if (dma_pick(a, s, &dt)) { dma_fill_tiling(a, dt); return; }
@@ -407,6 +409,12 @@ double launch_conv(const ConvArgs& a_in, const ConvShape& s, hipStream_t st) {
         if (a.nsrc >= 1 && a.nsrc <= 3 && x3_pick(a, s, &x3t)) {
             x3_fill_tiling(a, x3t);
             x3_launch_conv(a, x3t, st);
+            return 2.0 * a.N * (double)a.Hout * a.Wout * (double)a.Cout * a.Cin * s.KS * s.KS;
+        }
+        int x3d_mt;
+        if (a.nsrc >= 1 && a.nsrc <= 3 && x3d_pick(a, s, &x3d_mt)) {
+            x3d_fill_tiling(a, x3d_mt);
+            x3d_launch_conv(a, s, x3d_mt, st);
             return 2.0 * a.N * (double)a.Hout * a.Wout * (double)a.Cout * a.Cin * s.KS * s.KS;
         }
         if (a.nsrc >= 1 && a.nsrc <= 3 && wino_pick(a, s, &wino_mt)) {

@@ -76,6 +76,13 @@ void x3h_trace_read(long long* host, int n);          // diagnostics: phase stam
 void x3h_trace_clear();
 void launch_x3h_weights(const float* w, void* o, int Cin, int KK, int CoutPad, hipStream_t st);
 void launch_x3h_weights_batched(const X3WDesc* d_descs, int n, long long max_elems, int max_cout_pad, hipStream_t st);
+// conv_x3d.hip (round 6): conv_x3h's arithmetic for the 16-column layers -- dilated 3x3 (ASPP), 3x3 dilation 1 (enc5.conv2), 1x1 (ASPP conv2);
+// weights in x3h format (launch_x3h_weights with KK = 9 / 1); mfma_mode 3 only
+bool x3d_pick(const ConvArgs& a, const ConvShape& s, int* MT);
+void x3d_fill_tiling(ConvArgs& a, int MT);
+void x3d_launch_conv(const ConvArgs& a, const ConvShape& s, int MT, hipStream_t st);
+bool x3d_aspp_eligible(const ConvArgs* c4, const ConvShape* s4);   // c4 / s4 in concat order: 1x1, dilation (4,2), (8,4), (12,6)
+void x3d_launch_aspp(const ConvArgs* c4, hipStream_t st);          // the four branch convs of an ASPP module in ONE launch
 void launch_upsample2x(const Tensor& x, float* out, hipStream_t st);   // dense [N][C][2H][2W], activated
 
 // ---- lstm.hip -----------------------------------------------------------------------------------

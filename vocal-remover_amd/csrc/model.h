@@ -198,6 +198,10 @@ private:
     std::deque<BN> bns;
     std::vector<BN*> bn_list;
     std::vector<Conv*> wino_list;                        // 3x3 stride-1 layers (conv_wino.hip)
+    struct PendingConv { ConvArgs a; ConvShape shp; double flops, bytes; };
+    std::vector<PendingConv>* conv_sink = nullptr;       // set: run_conv hands the launch to its caller instead of launching (ASPP branch group)
+    int x3d_mode = 2;                                    // option "conv_x3d": 0 off, 1 single launches, 2 + the ASPP branch group
+    std::vector<Conv*> x3d_list;                         // the ASPP branch convs conv_x3d.hip takes in mfma_mode 3: dilated 3x3, conv2 (1x1)
     float* wino_arena = nullptr;
     float* winot_arena = nullptr;                        // training: Winograd copies of the flipped/transposed weights
     std::map<const Param*, float*> winot_of;
@@ -207,6 +211,7 @@ private:
     char* x3_arena = nullptr;                            // mfma_mode 2: bf16-plane copies of the direct 3x3 stride-1 weights (conv_x3.hip)
     char* x3t_arena = nullptr;                           //              and of their flipped / transposed forms (data gradient)
     std::map<const Param*, void*> x3t_of;
+    std::map<const Param*, void*> x3dt_of;                // the same for x3d_list (fp16 planes, valid in mfma_mode 3 only)
     // deferred weight-gradient slab sums of one backward pass (launch_wgrad_reduce_batched, round 6)
     std::vector<WgReduceDesc> wred_host, wred_sent;
     WgReduceDesc* wred_dev = nullptr;

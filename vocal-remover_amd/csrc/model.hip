@@ -60,6 +60,7 @@ void Model::build_cba(Conv& L, const std::string& prefix, int nin, int nout_, in
     L.w = add_param(prefix + ".conv.0.weight", {nout_, nin, ks, ks}, PK_CONV, true);
     L.bn = add_bn(prefix + ".conv.1", nout_, 0);
     if (ks == 3 && stride == 1 && dh == 1 && dw == 1) wino_list.push_back(&L);
+    if (ks == 3 && stride == 1 && dh > 1) x3d_list.push_back(&L);         // the dilated ASPP branches (conv_x3d.hip)
 }
 
 // nets.BaseNet (lib/nets.py:10-24)
@@ -76,6 +77,7 @@ void Model::build_basenet(BaseNetL& B, const std::string& p, int nin, int c, int
     const int C8 = 8 * c;
     build_cba(B.aspp_pool, p + ".aspp.conv1.1", C8, C8, 1, 1, 0, 0, 1, 1, RELU);
     build_cba(B.aspp_c2, p + ".aspp.conv2", C8, C8, 1, 1, 0, 0, 1, 1, RELU);
+    x3d_list.push_back(&B.aspp_c2);                                        // (runs beside the dilated branches in their launch)
     const int dil[3][2] = {{4, 2}, {8, 4}, {12, 6}};
     for (int i = 0; i < 3; ++i)
         build_cba(B.aspp_d[i], p + ".aspp.conv" + std::to_string(i + 3), C8, C8, 3, 1, dil[i][0], dil[i][1], dil[i][0],
@@ -354,6 +356,10 @@ void Model::set_option(const std::string& name, int value) {
         if (value < -1 || value > 3) throw Error(-2, "mfma_mode: 0, 1, 2, 3 or -1 (default)");
         mfma_mode = value < 0 ? default_mfma_mode : value; affine_dirty = true;   // (the next eval forward refreshes the derived weight copies)
     }
+    else if (name == "conv_x3d") {                           // the 16-column layers on the fp16 pipe (conv_x3d.hip, mfma_mode 3): 0 off (conv_dma.hip as in round 5),
+        if (value < -1 || value > 2) throw Error(-2, "conv_x3d: 0, 1, 2 or -1 (default)");     // 1 one launch per conv, 2 (default) + the four ASPP branches in one launch
+        x3d_mode = value < 0 ? 2 : value;
+    }
     else if (name == "adam_reset") reset_adam_state();      // a freshly constructed torch.optim.Adam has no moments
     else if (name == "hip_graph" || name == "conv_x3p" || name == "wgrad_x3h" || name == "conv_x3b") {
         // options of round 4 whose kernels moved to tools/experiments in round 5: accepted and ignored, so that an older caller keeps
@@ -386,31 +392,43 @@ void Model::refresh_wino(bool with_dgrad) {
     static const bool x3_on = !(getenv("VR_CONV_X3") && atoi(getenv("VR_CONV_X3")) == 0);
     if (x3_mode() && x3_on) {
         // split-bf16 (mode 2) / split-fp16 (mode 3) copies of the DIRECT weights (conv_x3.hip takes every 3x3 stride-1 launch wide enough for its tiles)
+        // (x3d_list: the dilated 3x3 and 1x1 branch convs of the ASPP modules, conv_x3d.hip -- fp16 planes only, filled in mode 3)
         if (!x3_arena) {
             size_t total = 0;
             for (Conv* L : wino_list) total += x3_weights_bytes(L->Cin, 9, L->CoutPad);
+            for (Conv* L : x3d_list) total += x3_weights_bytes(L->Cin, L->KS * L->KS, L->CoutPad);
             VR_HIP(hipMalloc(reinterpret_cast<void**>(&x3_arena), total ? total : 16));
             size_t off = 0;
             for (Conv* L : wino_list) { L->x3w = x3_arena + off; off += x3_weights_bytes(L->Cin, 9, L->CoutPad); }
+            for (Conv* L : x3d_list) { L->x3w = x3_arena + off; off += x3_weights_bytes(L->Cin, L->KS * L->KS, L->CoutPad); }
         }
         {
             std::vector<X3WDesc> d;
             for (Conv* L : wino_list) d.push_back(X3WDesc{L->w->dev, L->x3w, L->Cin, 9, L->CoutPad});
+            if (mfma_mode == 3)
+                for (Conv* L : x3d_list) d.push_back(X3WDesc{L->w->dev, L->x3w, L->Cin, L->KS * L->KS, L->CoutPad});
             run_x3_batch(xb_fwd, d);
         }
         if (with_dgrad) {
             if (!x3t_arena) {
                 size_t total = 0;
                 for (Conv* L : wino_list) total += x3_weights_bytes(L->Cout, 9, cin_pad(L));
+                for (Conv* L : x3d_list) total += x3_weights_bytes(L->Cout, L->KS * L->KS, cin_pad(L));
                 VR_HIP(hipMalloc(reinterpret_cast<void**>(&x3t_arena), total ? total : 16));
                 size_t off = 0;
                 for (Conv* L : wino_list) { x3t_of[L->w] = x3t_arena + off; off += x3_weights_bytes(L->Cout, 9, cin_pad(L)); }
+                for (Conv* L : x3d_list) { x3dt_of[L->w] = x3t_arena + off; off += x3_weights_bytes(L->Cout, L->KS * L->KS, cin_pad(L)); }
             }
             std::vector<X3WDesc> d;
             for (Conv* L : wino_list) {
                 auto it = wt_of.find(L->w);
                 if (it != wt_of.end()) d.push_back(X3WDesc{it->second, x3t_of[L->w], L->Cout, 9, cin_pad(L)});
             }
+            if (mfma_mode == 3)
+                for (Conv* L : x3d_list) {
+                    auto it = wt_of.find(L->w);
+                    if (it != wt_of.end()) d.push_back(X3WDesc{it->second, x3dt_of[L->w], L->Cout, L->KS * L->KS, cin_pad(L)});
+                }
             run_x3_batch(xb_bwd, d);
         }
     }
@@ -768,6 +786,7 @@ Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs_in, int N, cons
     a.wino = (training && !train_wino) ? nullptr : L.wino;   // (null until the first refresh_wino())
     a.wino6 = (a.wino && mfma_mode == 2) ? L.wino6 : nullptr;
     a.x3w = (x3_mode() && !(training && !train_wino)) ? L.x3w : nullptr;
+    if (!x3d_mode && a.Win == 16) a.x3w = nullptr;          // (16-column layers: only conv_x3d.hip reads the planes)
     a.bf16 = mfma_mode;
     Tensor o;
     if (batch_as_h) {
@@ -797,7 +816,14 @@ Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs_in, int N, cons
         npt = conv_part_count(a, shp);
         a.part = ws.allocf(npt * L.Cout * 2);
     }
-    if (!dry) {
+    if (!dry && conv_sink && !stats) {
+        // the caller launches this conv together with its siblings (ASPP branches: one conv_x3d launch for the four)
+        PendingConv pc;
+        pc.a = a; pc.shp = shp;
+        pc.flops = 2.0 * N * (double)a.Hout * a.Wout * (double)L.Cout * L.Cin * L.KS * L.KS;
+        pc.bytes = conv_alg_bytes(L, a, N, batch_as_h);
+        conv_sink->push_back(pc);
+    } else if (!dry) {
         const double flops = 2.0 * N * (double)(batch_as_h ? 1 : a.Hout) * a.Wout * (double)L.Cout * L.Cin * L.KS * L.KS;
         record_begin(0, flops);
         if (profiling) {
@@ -961,7 +987,11 @@ Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, co
     // Eval, stage 3: the four branch convs are independent and each fills < 256 CUs at 1/16 resolution --
     // two of them go to the idle side stream.
     static const bool aspp_fork = !getenv("VR_NO_ASPP_FORK");
-    const bool afk = aspp_fork && !serial && !training && !dry && !profiling && side_stream != nullptr && !band_fork_active;
+    // Eval, mfma_mode 3 (round 6): the four branch convs go out as ONE launch on the fp16 matrix pipe (conv_x3d.hip: blockIdx.y = branch).
+    // They are collected first; if any of them does not qualify (another mode, VR_ASPP_FUSED=0) each is launched on its own as before.
+    std::vector<PendingConv> pend;
+    const bool group = !training && !dry && mfma_mode == 3 && x3d_mode == 2;
+    const bool afk = aspp_fork && !serial && !training && !dry && !profiling && side_stream != nullptr && !band_fork_active && !group;
     hipStream_t aspp_main = stream;
     // (Round 5, measured and removed: every branch on its own stream -- three auxiliary streams per lane, in every stage -- made the
     // inference step 12.4 ms instead of 8.65, also with 8 or 16 hardware queues: each extra fork / join pair costs more than the overlap
@@ -977,7 +1007,34 @@ Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, co
         v.p = dry ? cat4.p : cat4.p + (long long)j * C8 * cat4.sC;
         if (taping() && !dry) v.g = cat4.g + (long long)j * C8 * cat4.sC;
         if (afk) stream = (j & 1) ? side_stream : aspp_main;
-        try { run_conv(*branch[j], {SrcSpec{x5}}, N, &v, nullptr, false); } catch (...) { stream = aspp_main; throw; }
+        if (group) conv_sink = &pend;
+        try { run_conv(*branch[j], {SrcSpec{x5}}, N, &v, nullptr, false); } catch (...) { stream = aspp_main; conv_sink = nullptr; throw; }
+        conv_sink = nullptr;
+    }
+    if (group) {
+        VR_CHECK(pend.size() == 4, -3, "ASPP: four branch convs expected");
+        ConvArgs c4[4];
+        ConvShape s4[4];
+        double flops = 0.0, bytes = 0.0;
+        for (int j = 0; j < 4; ++j) { c4[j] = pend[j].a; s4[j] = pend[j].shp; flops += pend[j].flops; bytes += pend[j].bytes; }
+        if (x3d_aspp_eligible(c4, s4)) {
+            record_begin(0, flops);
+            if (profiling) {
+                char tag[160];
+                snprintf(tag, sizeof tag, "%s.aspp.conv2-5 k1+3x(k3 d4/8/12) ci%d co%d %dx%dx%d", p.c_str(), C8, C8, N, x5.H, x5.W);
+                // (the four read the same input: counted once)
+                record_note(bytes - 3.0 * 4.0 * (double)N * C8 * x5.H * x5.W, tag);
+            }
+            x3d_launch_aspp(c4, stream);
+            record_end();
+        } else {
+            for (int j = 0; j < 4; ++j) {
+                record_begin(0, pend[j].flops);
+                if (profiling) record_note(pend[j].bytes, branch[j]->name.c_str());
+                launch_conv(c4[j], s4[j], stream);
+                record_end();
+            }
+        }
     }
     if (afk) {
         stream = aspp_main;
@@ -1576,7 +1633,12 @@ void Model::debug_conv(const float* x, int N, int Cin, int H, int W, const float
     float* dwino = nullptr;
     void* dwino6 = nullptr;
     void* dx3w = nullptr;
-    if (want_wino) {
+    if (want_wino && mfma_mode == 3 && stride == 1 && (KS == 1 || dh > 1)) {
+        // conv_x3d.hip's layers (dilated 3x3, 1x1 at 16 columns): fp16-plane weights only
+        VR_HIP(hipMalloc(&dx3w, x3_weights_bytes(Cin, KK, CoutPad)));
+        launch_x3h_weights(dw_, dx3w, Cin, KK, CoutPad, stream);
+        a.x3w = dx3w;
+    } else if (want_wino) {
         VR_CHECK(KS == 3 && stride == 1 && dh == 1 && dw == 1, -2, "Winograd weights exist for 3x3 stride-1 convs only");
         VR_HIP(hipMalloc(&dwino, (size_t)Cin * 16 * CoutPad * 4));
         launch_wino_weights(dw_, dwino, Cin, CoutPad, stream);

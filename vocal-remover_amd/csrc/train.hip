@@ -210,6 +210,9 @@ void Model::bwd_conv(TapeRec& r) {
     {
         auto itx = x3t_of.find(L.w);
         d.x3w = (!dry && train_wino && x3_mode() && itx != x3t_of.end()) ? itx->second : nullptr;
+        auto itd = x3dt_of.find(L.w);                     // dilated 3x3 / 1x1 ASPP branches (conv_x3d.hip)
+        if (!dry && train_wino && mfma_mode == 3 && itd != x3dt_of.end()) d.x3w = itd->second;
+        if (!x3d_mode && f.Win == 16) d.x3w = nullptr;
     }
     d.bias = nullptr;
     d.bf16 = mfma_mode;
@@ -785,6 +788,11 @@ void Model::debug_conv_bwd(const float* x, int N, int Cin, int H, int W, const f
             x3t_of[&P] = dx3t;
         }
     }
+    if (stride == 1 && (KS == 1 || dh > 1) && train_wino && mfma_mode == 3) {      // conv_x3d.hip's layers (16-column images)
+        VR_HIP(hipMalloc(&dx3t, x3_weights_bytes(Cout, KK, CinPad)));
+        launch_x3h_weights(dwt, dx3t, Cout, KK, CinPad, stream);
+        x3dt_of[&P] = dx3t;
+    }
     float* ds2w = nullptr;                    // stride-2 3x3: also exercise the parity-class data gradient
     if (KS == 3 && stride == 2 && dh == 1 && dw == 1) {
         VR_HIP(hipMalloc(&ds2w, (size_t)4 * Cout * 9 * CinPad * sizeof(float)));
@@ -823,6 +831,7 @@ void Model::debug_conv_bwd(const float* x, int N, int Cin, int H, int W, const f
     s2w_of.erase(&P);
     winot_of.erase(&P);
     x3t_of.erase(&P);
+    x3dt_of.erase(&P);
     hipFree(ds2w); hipFree(dwinot); hipFree(dx3t);
     hipFree(dx); hipFree(dgx); hipFree(dwk); hipFree(dwt); hipFree(dgw); hipFree(dzd); hipFree(daff); hipFree(dfd);
 }
