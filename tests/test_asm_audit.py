@@ -54,3 +54,12 @@ def test_no_instruction_touches_an_in_flight_asm_load(tmp_path):
         # vmcnt arithmetic: it is the tool that caught hipcc copying in-flight registers of the parked ping-pong kernel
         r = subprocess.run([sys.executable, AUDIT2, asm, 'conv_x3h_kernel' + inst], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and ' 0 reports' in r.stdout, r.stdout[-2000:]
+    # conv_x3d.hip (round 6): the same loads and waits behind a dilated halo tile; every single-conv instantiation.  (The ASPP kernel holds
+    # four of these bodies behind a branch on blockIdx.y: the linear scan concatenates mutually exclusive paths and reports across them.)
+    asm = _asm(tmp_path, 'conv_x3d.hip')
+    rows, out = _audit(asm, 'conv_x3d_kernel')
+    assert len(rows) == 10, out[-2000:]
+    for name, (loads, bad) in rows.items():
+        assert loads >= 100 and bad == 0, (name, loads, bad, out[-2000:])
+    r = subprocess.run([sys.executable, AUDIT2, asm, 'conv_x3d_kernel'], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.count(' 0 reports') == 10, r.stdout[-2000:]

@@ -1657,6 +1657,7 @@ void Model::debug_conv(const float* x, int N, int Cin, int H, int W, const float
             a.x3w = dx3w;
         }
     }
+    if (!x3d_mode && Win == 16) a.x3w = nullptr;            // option conv_x3d 0: the fp32-pipe kernels for the 16-column layers
     a.dst[0] = ConvDst{dout, (long long)Hout * Wout * Cout, (long long)Hout * Wout, (long long)Wout, 0};
     a.d1 = a.d2 = 1 << 30;
     a.N = N; a.Hout = Hout; a.Wout = Wout; a.Hin = Hin; a.Win = Win; a.pad_h = pad_h; a.pad_w = pad_w;
