@@ -227,41 +227,55 @@ def test_aspp_branches_in_one_launch_through_the_network(vr, net):
 
 def test_train_step_with_conv_x3d_matches_the_fp32_pipe(vr, net):
     """A train step at 256 frames: forward (BatchNorm statistics from conv_x3d's partial sums) and data gradients of the ASPP branches and
-    enc5.conv2 on conv_x3d against the same step with conv_x3d off -- loss to 1e-6 relative, every gradient tensor within 2e-2 of its
-    scale, cosine > 0.9999."""
+    enc5.conv2 on conv_x3d (A) against the same step with conv_x3d off (B).  The loss must agree to 1e-6 relative.  The gradients of two
+    fp32-grade evaluations differ by rounding noise carried back through five cascaded nets (ReLU masks, BatchNorm): the yardstick is a
+    CONTROL pair of fp32-grade evaluations that never touch conv_x3d -- B against C = conv_x3d off and `train_winograd` 0 (the fused-loader
+    kernels of rounds 1-2 everywhere) -- and A must sit as close to B as C does (3 x per tensor class, measured over all tensors)."""
     model, sd = net
     X, y = train_step.synth_batch(2, T=256, n_fft=512, seed=8)
     res = {}
     try:
-        for mode in (2, 0):
+        for name, x3d, wino in (('A', 2, 1), ('B', 0, 1), ('C', 0, 0)):
             model.load_state_dict(sd)
             model.to(torch.device('cuda:0'))
             model.train()
-            model.set_option('conv_x3d', mode)
+            model.set_option('conv_x3d', x3d)
+            model.set_option('train_winograd', wino)
             model.set_dropout_masks(None)                # (the library's generator is keyed on the number of forwards so far: off for an A / B)
             model.zero_grad()
             loss = model.train_step(X.to('cuda:0'), y.to('cuda:0'), 1)
-            res[mode] = (float(loss), {k: v.numpy().copy() for k, v in model.grads().items()})
+            res[name] = (float(loss), {k: v.numpy().astype(np.float64) for k, v in model.grads().items()})
     finally:
         model.set_option('conv_x3d', -1)
+        model.set_option('train_winograd', 1)
         model.set_dropout_masks(0)
         model.load_state_dict(sd)
         model.to(torch.device('cuda:0'))
         model.eval()
-    l2, l0 = res[2][0], res[0][0]
-    print('loss: conv_x3d %.8f, off %.8f' % (l2, l0))
-    assert abs(l2 - l0) <= 1e-6 * abs(l0) + 1e-7
-    worst, worst_cos = 0.0, 1.0
-    for k, g2 in res[2][1].items():
-        g0 = res[0][1][k]
-        sc = float(np.abs(g0).max())
-        if sc == 0.0:
-            continue
-        worst = max(worst, float(np.abs(g2 - g0).max()) / sc)
-        if g0.size >= 16:
-            cos = float((g2.astype(np.float64) * g0).sum() / (np.linalg.norm(g2.astype(np.float64)) * np.linalg.norm(g0.astype(np.float64)) + 1e-300))
-            worst_cos = min(worst_cos, cos)
-    # (two fp32-grade evaluations of the same step: the differences are rounding noise carried back through five nets -- the first
-    # layer's weight gradient moves most; tests/test_gpu_b16.py holds the step against the fp32 / fp64 oracles)
-    print('largest gradient difference: %.2e of the tensor scale; smallest cosine %.7f' % (worst, worst_cos))
-    assert worst < 2e-2 and worst_cos > 0.9999
+    la, lb, lc = res['A'][0], res['B'][0], res['C'][0]
+    print('loss: conv_x3d %.8f, off %.8f, control %.8f' % (la, lb, lc))
+    assert abs(la - lb) <= 1e-6 * abs(lb) + 1e-7 and abs(lc - lb) <= 1e-5 * abs(lb) + 1e-7
+    gmax = max(float(np.abs(g).max()) for g in res['B'][1].values())
+
+    def spread(p, q):
+        """(largest max-abs difference / tensor scale, smallest cosine, rms over tensors of the relative difference)"""
+        worst, wcos, acc, n = 0.0, 1.0, 0.0, 0
+        for k, gq in res[q][1].items():
+            gp = res[p][1][k]
+            sc = float(np.abs(gq).max())
+            # (a Linear bias in front of BatchNorm1d has an exactly zero gradient: what the kernels leave there is rounding noise)
+            if sc < 1e-5 * gmax:
+                continue
+            d = float(np.abs(gp - gq).max()) / sc
+            worst = max(worst, d)
+            acc += d * d
+            n += 1
+            if gq.size >= 16:
+                wcos = min(wcos, float((gp * gq).sum() / (np.linalg.norm(gp) * np.linalg.norm(gq) + 1e-300)))
+        return worst, wcos, (acc / max(n, 1)) ** 0.5
+
+    wa, ca, ra = spread('A', 'B')
+    wc, cc, rc = spread('C', 'B')
+    print('conv_x3d vs off:        largest difference %.2e of a tensor scale, smallest cosine %.6f, rms %.2e' % (wa, ca, ra))
+    print('control (other fp32 kernels) vs off: largest %.2e, smallest cosine %.6f, rms %.2e' % (wc, cc, rc))
+    assert wa <= 3.0 * wc + 1e-4 and ra <= 3.0 * rc + 1e-5 and (1.0 - ca) <= 3.0 * (1.0 - cc) + 1e-6

@@ -501,7 +501,7 @@ bool x3d_aspp_eligible(const ConvArgs* c, const ConvShape* s) {
     int mt[4];
     for (int j = 0; j < 4; ++j) {
         if (!x3d_pick(c[j], s[j], &mt[j])) return false;
-        if (c[j].N != c[0].N || c[j].Hout != c[0].Hout || c[j].CoutPad != c[0].CoutPad || c[j].part) return false;
+        if (c[j].N != c[0].N || c[j].Hout != c[0].Hout || c[j].CoutPad != c[0].CoutPad) return false;
     }
     return s[0].KS == 1 && s[1].KS == 3 && s[1].dil_h == 4 && s[2].KS == 3 && s[2].dil_h == 8 && s[3].KS == 3 && s[3].dil_h == 12;
 }

@@ -198,7 +198,7 @@ private:
     std::deque<BN> bns;
     std::vector<BN*> bn_list;
     std::vector<Conv*> wino_list;                        // 3x3 stride-1 layers (conv_wino.hip)
-    struct PendingConv { ConvArgs a; ConvShape shp; double flops, bytes; };
+    struct PendingConv { ConvArgs a; ConvShape shp; double flops, bytes; bool stats; BNFinalizeArgs fin; BN* bn; };
     std::vector<PendingConv>* conv_sink = nullptr;       // set: run_conv hands the launch to its caller instead of launching (ASPP branch group)
     int x3d_mode = 2;                                    // option "conv_x3d": 0 off, 1 single launches, 2 + the ASPP branch group
     std::vector<Conv*> x3d_list;                         // the ASPP branch convs conv_x3d.hip takes in mfma_mode 3: dilated 3x3, conv2 (1x1)

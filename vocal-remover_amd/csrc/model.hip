@@ -816,12 +816,22 @@ Tensor Model::run_conv(Conv& L, const std::vector<SrcSpec>& srcs_in, int N, cons
         npt = conv_part_count(a, shp);
         a.part = ws.allocf(npt * L.Cout * 2);
     }
-    if (!dry && conv_sink && !stats) {
-        // the caller launches this conv together with its siblings (ASPP branches: one conv_x3d launch for the four)
-        PendingConv pc;
+    if (!dry && conv_sink) {
+        // the caller launches this conv together with its siblings (ASPP branches: one conv_x3d launch for the four) and, in training,
+        // finalises the BatchNorm statistics behind it
+        PendingConv pc{};
         pc.a = a; pc.shp = shp;
         pc.flops = 2.0 * N * (double)a.Hout * a.Wout * (double)L.Cout * L.Cin * L.KS * L.KS;
         pc.bytes = conv_alg_bytes(L, a, N, batch_as_h);
+        pc.stats = stats; pc.bn = L.bn;
+        if (stats) {
+            BNFinalizeArgs& f = pc.fin;
+            f.part = a.part; f.nparts = (int)npt; f.pstride = L.Cout * 2;
+            f.count = (double)N * a.Hout * a.Wout;
+            f.w = L.bn->w->dev; f.b = L.bn->b->dev; f.rm = L.bn->rm->dev; f.rv = L.bn->rv->dev;
+            f.affine = L.bn->affine; f.save_mean = L.bn->save_mean; f.save_invstd = L.bn->save_invstd;
+            f.C = L.Cout; f.eps = 1e-5f; f.momentum = 0.1f; f.broadcast = 0;
+        }
         conv_sink->push_back(pc);
     } else if (!dry) {
         const double flops = 2.0 * N * (double)(batch_as_h ? 1 : a.Hout) * a.Wout * (double)L.Cout * L.Cin * L.KS * L.KS;
@@ -984,13 +994,25 @@ Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, co
     if (taping()) cat4.g = galloc((size_t)N * cat4.C * x5.H * x5.W, false);
     if (training) { cat4.aff0 = B.aspp_aff; cat4.slope = 0.f; }      // eval: the branch convs store final activations
     Conv* branch[4] = {&B.aspp_c2, &B.aspp_d[0], &B.aspp_d[1], &B.aspp_d[2]};
+    // Training: the four branches read the same activated tensor -- materialised ONCE here (run_conv would do it once per branch); the plain
+    // copy shares x5's gradient buffer, so the four data gradients still meet in x5.g
+    Tensor x5b = x5;
+    {
+        static const bool mat_enabled = !getenv("VR_NO_TRAIN_MAT");
+        if (training && mat_enabled && (x5.aff0 || x5.aff1 || x5.post || x5.slope != 1.f)) {
+            float* buf = ws.allocf((size_t)N * C8 * x5.H * x5.W);
+            if (!dry) launch_materialize(x5, buf, stream);
+            x5b.p = buf; x5b.aff0 = x5b.aff1 = nullptr; x5b.post = nullptr; x5b.slope = 1.f; x5b.hsplit = 1 << 30;
+            x5b.sH = x5.W; x5b.sC = (long long)x5.H * x5.W; x5b.sN = x5b.sC * C8;
+        }
+    }
     // Eval, stage 3: the four branch convs are independent and each fills < 256 CUs at 1/16 resolution --
     // two of them go to the idle side stream.
     static const bool aspp_fork = !getenv("VR_NO_ASPP_FORK");
     // Eval, mfma_mode 3 (round 6): the four branch convs go out as ONE launch on the fp16 matrix pipe (conv_x3d.hip: blockIdx.y = branch).
     // They are collected first; if any of them does not qualify (another mode, VR_ASPP_FUSED=0) each is launched on its own as before.
     std::vector<PendingConv> pend;
-    const bool group = !training && !dry && mfma_mode == 3 && x3d_mode == 2;
+    const bool group = !dry && mfma_mode == 3 && x3d_mode == 2 && !(training && !train_wino);
     const bool afk = aspp_fork && !serial && !training && !dry && !profiling && side_stream != nullptr && !band_fork_active && !group;
     hipStream_t aspp_main = stream;
     // (Round 5, measured and removed: every branch on its own stream -- three auxiliary streams per lane, in every stage -- made the
@@ -1008,7 +1030,7 @@ Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, co
         if (taping() && !dry) v.g = cat4.g + (long long)j * C8 * cat4.sC;
         if (afk) stream = (j & 1) ? side_stream : aspp_main;
         if (group) conv_sink = &pend;
-        try { run_conv(*branch[j], {SrcSpec{x5}}, N, &v, nullptr, false); } catch (...) { stream = aspp_main; conv_sink = nullptr; throw; }
+        try { run_conv(*branch[j], {SrcSpec{x5b}}, N, &v, nullptr, false); } catch (...) { stream = aspp_main; conv_sink = nullptr; throw; }
         conv_sink = nullptr;
     }
     if (group) {
@@ -1035,6 +1057,11 @@ Tensor Model::run_basenet(BaseNetL& B, const std::vector<SrcSpec>& in, int N, co
                 record_end();
             }
         }
+        for (int j = 0; j < 4; ++j)
+            if (pend[j].stats) {
+                launch_bn_finalize(pend[j].fin, stream);
+                pend[j].bn->nbt->nbt += 1;
+            }
     }
     if (afk) {
         stream = aspp_main;

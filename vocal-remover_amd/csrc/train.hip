@@ -407,7 +407,8 @@ void Model::backward() {
 void Model::flush_wgrad_sums() {
     if (wred_host.empty()) return;
     long long blocks = 0;
-    for (WgReduceDesc& d : wred_host) { d.blk0 = blocks; blocks += (d.n + 63) / 64; }
+    const int vec = wgrad_reduce_vec(wred_host.data(), (int)wred_host.size());
+    for (WgReduceDesc& d : wred_host) { d.blk0 = blocks; blocks += (d.n / vec + 63) / 64; }
     const size_t bytes = wred_host.size() * sizeof(WgReduceDesc);
     hipStream_t st = wgrad_on_side ? side_stream : stream;
     if (wred_cap < wred_host.size()) {
@@ -422,7 +423,7 @@ void Model::flush_wgrad_sums() {
         VR_HIP(hipMemcpy(wred_dev, wred_host.data(), bytes, hipMemcpyHostToDevice));
         wred_sent = wred_host;
     }
-    launch_wgrad_reduce_batched(wred_dev, (int)wred_host.size(), blocks, st);
+    launch_wgrad_reduce_batched(wred_dev, (int)wred_host.size(), blocks, vec, st);
     wred_host.clear();
 }
 

@@ -193,7 +193,8 @@ double launch_wgrad(const WgradArgs& a, const ConvShape& s, float* grad_out, int
 // (the slabs live in the step's bump-allocated workspace until the next step).
 struct WgReduceDesc { const float* part; long long stride; float* out; long long n; int P; int accumulate; long long blk0; };
 void wgrad_defer_to(std::vector<WgReduceDesc>* sink);          // nullptr: launch_wgrad sums immediately again
-void launch_wgrad_reduce_batched(const WgReduceDesc* d_descs, int n, long long total_blocks, hipStream_t st);
+int wgrad_reduce_vec(const WgReduceDesc* host_descs, int n);    // 4: every slab / gradient is 16-byte aligned and sized (a block sums 256 elements), else 1 (64)
+void launch_wgrad_reduce_batched(const WgReduceDesc* d_descs, int n, long long total_blocks, int vec, hipStream_t st);
 size_t wgrad_scratch_floats(const WgradArgs& a, const ConvShape& s);
 
 // Returns the algorithmic FLOPs of the launch (2*MACs) for roofline accounting.

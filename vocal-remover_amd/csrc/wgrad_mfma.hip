@@ -505,41 +505,53 @@ static void wg_launch_ws(const WgradArgs& a, int MB, hipStream_t st) {
     else wg_launch_ws_inst<KS, S, TH, TW, 1>(a, st);
 }
 
-// the same sum for MANY layers in one launch: block b belongs to the descriptor d with d.blk0 <= b < next.blk0 (binary search over <= 128)
+// the same sum for MANY layers in one launch: block b belongs to the descriptor d with d.blk0 <= b < next.blk0 (binary search over <= 128).
+// VEC = 4: a thread sums FOUR neighbouring elements (16-byte loads, four slabs in flight per accumulator set -- the scalar form of the
+// first version streamed at ~0.3 TB/s: 690 us at the end of every train step, in front of Adam); per element the order of the additions
+// is wgrad_reduce_kernel's, so the sums stay bit-equal.  VEC = 1: slabs whose size or address is not a multiple of 16 bytes.
+template <int VEC>
 __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const WgReduceDesc* __restrict__ descs, int nd) {
-    __shared__ float red[4][64];
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    __shared__ vec_t red[4][64];
     int lo = 0, hi = nd - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if (descs[mid].blk0 <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const WgReduceDesc d = descs[lo];
-    const float* __restrict__ part = d.part;
-    const long long stride = d.stride;
+    const vec_t* __restrict__ part = reinterpret_cast<const vec_t*>(d.part);
+    const long long stride = d.stride / VEC, n = d.n / VEC;
     const int P = d.P;
     const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
     const long long i = ((long long)blockIdx.x - d.blk0) * 64 + e;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (i < d.n) {
+    vec_t s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
         int p = q;
         for (; p + 12 < P; p += 16) {
-            s0 += part[(long long)p * stride + i];
-            s1 += part[(long long)(p + 4) * stride + i];
-            s2 += part[(long long)(p + 8) * stride + i];
-            s3 += part[(long long)(p + 12) * stride + i];
+            const vec_t v0 = part[(long long)p * stride + i], v1 = part[(long long)(p + 4) * stride + i],
+                        v2 = part[(long long)(p + 8) * stride + i], v3 = part[(long long)(p + 12) * stride + i];
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
         }
         for (; p < P; p += 4) s0 += part[(long long)p * stride + i];
     }
     red[q][e] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (q == 0 && i < d.n) {
-        const float s = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);        // (the order of wgrad_reduce_kernel: bit-equal results)
-        d.out[i] = d.accumulate ? d.out[i] + s : s;
+    if (q == 0 && i < n) {
+        const vec_t s = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);        // (the order of wgrad_reduce_kernel: bit-equal results)
+        vec_t* o = reinterpret_cast<vec_t*>(d.out) + i;
+        *o = d.accumulate ? *o + s : s;
     }
 }
-void launch_wgrad_reduce_batched(const WgReduceDesc* d_descs, int n, long long total_blocks, hipStream_t st) {
+// blocks a descriptor takes in the batched launch (the caller lays the descriptors out back to back: WgReduceDesc::blk0)
+int wgrad_reduce_vec(const WgReduceDesc* h, int n) {
+    for (int j = 0; j < n; ++j)
+        if ((h[j].n & 3) || (h[j].stride & 3) || (reinterpret_cast<size_t>(h[j].part) & 15) || (reinterpret_cast<size_t>(h[j].out) & 15)) return 1;
+    return 4;
+}
+void launch_wgrad_reduce_batched(const WgReduceDesc* d_descs, int n, long long total_blocks, int vec, hipStream_t st) {
     if (n <= 0) return;
-    VR_LAUNCH(wgrad_reduce_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, d_descs, n);
+    if (vec == 4) VR_LAUNCH(wgrad_reduce_batched_kernel<4>, dim3((unsigned)total_blocks), dim3(256), 0, st, d_descs, n);
+    else VR_LAUNCH(wgrad_reduce_batched_kernel<1>, dim3((unsigned)total_blocks), dim3(256), 0, st, d_descs, n);
     VR_HIP(hipGetLastError());
 }
 

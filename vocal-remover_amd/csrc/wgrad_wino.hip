@@ -653,6 +653,11 @@ static bool ww_enabled() {
 bool wgrad_wino_pick(const WgradArgs& a, const ConvShape& s, int* CB_out, int* MT_out) {
     if (!ww_enabled() || !a.allow_wino) return false;
     if (!(s.KS == 3 && s.stride == 1 && s.dil_h == 1 && s.dil_w == 1)) return false;
+    // experiment knobs (round 6): layers with few input / output channels to the direct weight-gradient kernels -- the Winograd form
+    // transforms dz for a full 32-cout block and x for a full 32-channel block whatever the layer has
+    static const int min_cin = getenv("VR_WW_MIN_CIN") ? atoi(getenv("VR_WW_MIN_CIN")) : 0;
+    static const int min_cout = getenv("VR_WW_MIN_COUT") ? atoi(getenv("VR_WW_MIN_COUT")) : 0;
+    if (a.in.Cin < min_cin || a.Cout < min_cout) return false;
     if (a.in.pad_h != 1 || a.in.pad_w != 1 || a.in.Hout != a.in.Hin || a.in.Wout != a.in.Win) return false;
     if ((a.in.Win & 3) || a.in.Win < 16 || a.in.Hin < 2) return false;
     for (int i = 0; i < a.in.nsrc; ++i) {
@@ -681,7 +686,8 @@ void wgrad_wino_plan(WgradArgs& a, int CB, int MT) {
     a.nchunks = (a.in.Cin + CB - 1) / CB;
     a.nct = a.CoutPad / MT;
     a.part_stride = (long long)a.in.Cin * 9 * a.CoutPad;
-    long long P = 512 / ((long long)a.nchunks * a.nct);        // one workgroup per CU: two rounds of 256
+    static const int ptarget = getenv("VR_WW_PTARGET") ? atoi(getenv("VR_WW_PTARGET")) : 512;
+    long long P = ptarget / ((long long)a.nchunks * a.nct);    // one workgroup per CU: two rounds of 256
     if (P < 1) P = 1;
     if (P > a.npt) P = a.npt;
     const long long cap = (64LL << 20) / a.part_stride;       // scratch <= 256 MB
