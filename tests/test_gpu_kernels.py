@@ -42,7 +42,9 @@ def act(v, slope):
 
 
 @pytest.mark.parametrize('shape,slope,use_post', [((2, 16, 32, 64), 0.0, False), ((3, 5, 7, 10), 0.01, True),
-                                                  ((4, 1, 64, 32), 0.0, False), ((2, 40, 16, 16), 0.01, True)])
+                                                  ((4, 1, 64, 32), 0.0, False), ((2, 40, 16, 16), 0.01, True),
+                                                  # more than 16384 elements per channel: several reduce blocks per channel, the last one finalises
+                                                  ((4, 6, 128, 64), 0.01, True), ((16, 3, 64, 256), 0.0, False)])
 def test_batchnorm_train_forward_stats_and_backward(handle, shape, slope, use_post):
     nat, h = handle
     N, C, H, W = shape

@@ -111,6 +111,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
 }
 
 // pass 1b: finalize -> d(gamma), d(beta) into the gradient arena, coefficients (kA,kB,kC) for pass 2
+// (Round 6, built and measured: the channel's LAST reduce block doing this -- per-channel block counter, __threadfence() + atomicAdd per
+// block, 107 launches fewer per train step, results bit-equal -- made the step 55.0 -> 61.0 ms: an agent-scope release / acquire on
+// gfx950 writes back and invalidates the XCD's WHOLE L2 (buffer_wbl2 / buffer_inv sc1), once per block, under the streaming reads of this
+// pass and of the weight gradients on the other stream.  The counters must also be per stream: backward() runs two chains.  Reverted.)
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdArgs a, int nchunks) {
     const int c = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
@@ -765,8 +769,11 @@ __global__ void flip_transpose_kernel(const FlipDesc* descs) {
 // (ph, pw) the gradient is a stride-1 conv over dz whose tap t = (th, tw) (input offset th-1, tw-1) carries the
 // forward weight w[.][.][kh][kw]:   parity 0: th = 1 <- k = 1;   parity 1: th = 1 <- k = 2, th = 2 <- k = 0.
 //   w  [Cin][9][CoutPad] (forward layout)   ->   wc [4][Cout][9][CinPad]  (dz channel, tap, input channel)
-__global__ void s2_class_weights_kernel(const float* __restrict__ w, float* __restrict__ wc, int Cin, int Cout, int CoutPad,
-                                        int CinPad) {
+// (one launch for all stride-2 layers of the net: blockIdx.y = layer -- 20 launches of ~5 us per train step until round 6)
+__global__ void s2_class_weights_kernel(const S2WDesc* __restrict__ descs) {
+    const S2WDesc d = descs[blockIdx.y];
+    const float* __restrict__ w = d.w;
+    const int Cin = d.Cin, Cout = d.Cout, CoutPad = d.CoutPad, CinPad = d.CinPad;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long per = (long long)Cout * 9 * CinPad;
     if (gid >= 4 * per) return;
@@ -780,13 +787,12 @@ __global__ void s2_class_weights_kernel(const float* __restrict__ w, float* __re
     const int kw = pw == 0 ? (tw == 1 ? 1 : -1) : (tw == 1 ? 2 : (tw == 2 ? 0 : -1));
     float v = 0.f;
     if (kh >= 0 && kw >= 0 && ci < Cin) v = w[((long long)ci * 9 + kh * 3 + kw) * CoutPad + co];
-    wc[gid] = v;
+    d.wc[gid] = v;
 }
 
-void launch_s2_class_weights(const float* w, float* wc, int Cin, int Cout, int CoutPad, int CinPad, hipStream_t st) {
-    const long long n = 4LL * Cout * 9 * CinPad;
-    VR_LAUNCH(s2_class_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, wc, Cin, Cout, CoutPad,
-                       CinPad);
+void launch_s2_class_weights(const S2WDesc* d_descs, int n, long long max_elems, hipStream_t st) {
+    if (n <= 0) return;
+    VR_LAUNCH(s2_class_weights_kernel, dim3((unsigned)((max_elems + 255) / 256), (unsigned)n), dim3(256), 0, st, d_descs);
     VR_HIP(hipGetLastError());
 }
 

@@ -54,7 +54,8 @@ void thin16_fill_tiling(ConvArgs& a, int TH);
 void thin16_launch_conv(const ConvArgs& a, const ConvShape& s, int TH, hipStream_t st);
 bool s2d_fused_eligible(const ConvArgs& a);                       // conv_dma.hip: stride-2 data gradient, four parity classes in one launch
 void launch_s2d_fused(const ConvArgs& a, hipStream_t st);
-void launch_s2_class_weights(const float* w, float* wc, int Cin, int Cout, int CoutPad, int CinPad, hipStream_t st);
+struct S2WDesc { const float* w; float* wc; int Cin, Cout, CoutPad, CinPad; };          // one stride-2 layer; max_elems = max over layers of 4 * Cout * 9 * CinPad
+void launch_s2_class_weights(const S2WDesc* d_descs, int n, long long max_elems, hipStream_t st);
 void launch_wino_weights(const float* w, float* u, int Cin, int CoutPad, hipStream_t st);   // U = G g G^T
 struct WinoWDesc { const float* w; void* u; int Cin, CoutPad; };                              // one layer of a batched refresh
 void launch_wino_weights_batched(const WinoWDesc* d_descs, int n, long long max_elems, bool split6, hipStream_t st);

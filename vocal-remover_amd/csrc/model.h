@@ -285,6 +285,8 @@ private:
     float* s2w_arena = nullptr;                          // parity-class weights of the stride-2 convs' data gradients
     std::map<const Param*, float*> s2w_of;
     std::vector<Conv*> s2_list;
+    S2WDesc* d_s2w = nullptr;                            // descriptor table of launch_s2_class_weights (one launch for all of them)
+    long long s2w_max = 0;
     long long adam_step = 0;
     float* grad_of(const Param* p) { return p->grad_override ? p->grad_override : g_arena + (p->dev - p_arena); }
 public:

@@ -248,7 +248,7 @@ Model::~Model() {
     hipFree(wire_buf);
     if (stream) hipStreamSynchronize(stream);
     hipFree(p_arena); hipFree(b_arena); hipFree(d_fold);
-    hipFree(ws.base); hipFree(io.base); hipFree(gs.base); hipFree(wino_arena); hipFree(winot_arena); hipFree(wino6_arena); hipFree(winot6_arena); hipFree(x3_arena); hipFree(x3t_arena); hipFree(xb_fwd.dev); hipFree(xb_bwd.dev); hipFree(wb_fwd.dev); hipFree(wb_bwd.dev); hipFree(wb_fwd6.dev); hipFree(wb_bwd6.dev); hipFree(aug_buf); hipFree(wred_dev);
+    hipFree(ws.base); hipFree(io.base); hipFree(gs.base); hipFree(wino_arena); hipFree(winot_arena); hipFree(wino6_arena); hipFree(winot6_arena); hipFree(x3_arena); hipFree(x3t_arena); hipFree(xb_fwd.dev); hipFree(xb_bwd.dev); hipFree(wb_fwd.dev); hipFree(wb_bwd.dev); hipFree(wb_fwd6.dev); hipFree(wb_bwd6.dev); hipFree(aug_buf); hipFree(wred_dev); hipFree(d_s2w);
     for (BaseNetL& B : nets_) hipFree(B.lstm.bias_sum);
     hipFree(g_arena); hipFree(m_arena); hipFree(v_arena); hipFree(wt_arena); hipFree(d_flip); hipFree(dropout_buf);
     hipFree(plan.twiddle); hipFree(plan.window);

@@ -59,7 +59,15 @@ void Model::ensure_train_state() {
         if (tot) {
             VR_HIP(hipMalloc(&s2w_arena, tot * sizeof(float)));
             size_t o = 0;
-            for (Conv* L : s2_list) { s2w_of[L->w] = s2w_arena + o; o += (size_t)4 * L->Cout * 9 * round_up32(L->Cin); }
+            std::vector<S2WDesc> sd;
+            for (Conv* L : s2_list) {
+                s2w_of[L->w] = s2w_arena + o;
+                sd.push_back(S2WDesc{L->w->dev, s2w_arena + o, L->Cin, L->Cout, L->CoutPad, round_up32(L->Cin)});
+                s2w_max = std::max(s2w_max, (long long)4 * L->Cout * 9 * round_up32(L->Cin));
+                o += (size_t)4 * L->Cout * 9 * round_up32(L->Cin);
+            }
+            VR_HIP(hipMalloc(reinterpret_cast<void**>(&d_s2w), sd.size() * sizeof(S2WDesc)));
+            VR_HIP(hipMemcpy(d_s2w, sd.data(), sd.size() * sizeof(S2WDesc), hipMemcpyHostToDevice));
         }
     }
     n_flip = (int)descs.size();
@@ -438,7 +446,7 @@ void Model::train_fwd_bwd_api(const float* X, const float* Y, bool on_dev, int B
     // flipped/transposed weights for the data gradients + Winograd-domain copies of both, once per step
     // (before the planning dry run: the kernel choice, hence the partial-statistics layout, depends on them)
     launch_flip_transpose(d_flip, n_flip, stream);
-    for (Conv* L : s2_list) launch_s2_class_weights(L->w->dev, s2w_of[L->w], L->Cin, L->Cout, L->CoutPad, round_up32(L->Cin), stream);
+    launch_s2_class_weights(d_s2w, (int)s2_list.size(), s2w_max, stream);
     refresh_wino(true);
     const size_t io_floats = (size_t)B * 2 * output_bin * T;
     const int Hm = max_bin;
@@ -531,7 +539,7 @@ void Model::forward_train_api(const float* X, bool on_dev, int B, int T, float* 
     graph_valid = false;
     ensure_train_state();
     launch_flip_transpose(d_flip, n_flip, stream);
-    for (Conv* L : s2_list) launch_s2_class_weights(L->w->dev, s2w_of[L->w], L->Cin, L->Cout, L->CoutPad, round_up32(L->Cin), stream);
+    launch_s2_class_weights(d_s2w, (int)s2_list.size(), s2w_max, stream);
     refresh_wino(true);
     const size_t io_floats = (size_t)B * 2 * output_bin * T;
     const int Hm = max_bin;
@@ -795,9 +803,13 @@ void Model::debug_conv_bwd(const float* x, int N, int Cin, int H, int W, const f
         x3dt_of[&P] = dx3t;
     }
     float* ds2w = nullptr;                    // stride-2 3x3: also exercise the parity-class data gradient
+    S2WDesc* ds2d = nullptr;
     if (KS == 3 && stride == 2 && dh == 1 && dw == 1) {
         VR_HIP(hipMalloc(&ds2w, (size_t)4 * Cout * 9 * CinPad * sizeof(float)));
-        launch_s2_class_weights(dwk, ds2w, Cin, Cout, CoutPad, CinPad, stream);
+        const S2WDesc sd{dwk, ds2w, Cin, Cout, CoutPad, CinPad};
+        VR_HIP(hipMalloc(reinterpret_cast<void**>(&ds2d), sizeof(S2WDesc)));
+        VR_HIP(hipMemcpy(ds2d, &sd, sizeof(S2WDesc), hipMemcpyHostToDevice));
+        launch_s2_class_weights(ds2d, 1, 4LL * Cout * 9 * CinPad, stream);
         s2w_of[&P] = ds2w;
     }
     Tensor t;
@@ -833,7 +845,7 @@ void Model::debug_conv_bwd(const float* x, int N, int Cin, int H, int W, const f
     winot_of.erase(&P);
     x3t_of.erase(&P);
     x3dt_of.erase(&P);
-    hipFree(ds2w); hipFree(dwinot); hipFree(dx3t);
+    hipFree(ds2w); hipFree(ds2d); hipFree(dwinot); hipFree(dx3t);
     hipFree(dx); hipFree(dgx); hipFree(dwk); hipFree(dwt); hipFree(dgw); hipFree(dzd); hipFree(daff); hipFree(dfd);
 }
 
