@@ -87,8 +87,10 @@ def test_every_kernel_of_the_library_is_reached_by_a_documented_shape_or_option(
             col.run('train step, %d frames' % T, h, trn(T))
         # the reference's crop size: 256 frames -> 16 columns at 1/16 resolution, where conv_x3d.hip takes the ASPP branch convs (one launch
         # for the four in eval) and enc5.conv2; training: one launch per conv, forward and data gradient
+        small.set_option('mfma_mode', 3)                  # (pinned: VR_MFMA_MODE may have given the handle another default)
         col.run('eval, 256 frames', h, fwd(256))
         col.run('train step, 256 frames', h, trn(256))
+        small.set_option('mfma_mode', -1)
         small.set_dropout_masks(None)
         col.run('train step without dropout', h, trn(160))
         # the other arithmetic modes: 0 = fp32 MFMA everywhere (Winograd forward), 1 = bf16 operands, 2 = six bf16 products

@@ -203,12 +203,14 @@ def test_aspp_branches_in_one_launch_through_the_network(vr, net):
     xd = x.to('cuda:0')
     got, names = {}, {}
     try:
+        model.set_option('mfma_mode', 3)                  # (conv_x3d exists in the fp16-split mode only: also when VR_MFMA_MODE sets another default)
         for mode in (2, 1, 0):
             model.set_option('conv_x3d', mode)
             got[mode] = model.predict_mask(xd).cpu().numpy()
             names[mode] = _kernels_of(vr, model, lambda: model.predict_mask(xd))
     finally:
         model.set_option('conv_x3d', -1)
+        model.set_option('mfma_mode', -1)
     for mode in (2, 1, 0):
         err = float(np.abs(got[mode] - want).max())
         print('conv_x3d %d: max-abs error vs the oracle %.2e' % (mode, err))
@@ -221,7 +223,11 @@ def test_aspp_branches_in_one_launch_through_the_network(vr, net):
     assert not any('conv_x3d_aspp_kernel' in n for n in names[1]) and any('conv_x3d_kernel<9, 12, 6' in n for n in names[1]), names[1]
     assert not any('conv_x3d' in n for n in names[0]), names[0]
     # bit-reproducible from run to run
-    again = model.predict_mask(xd).cpu().numpy()
+    try:
+        model.set_option('mfma_mode', 3)
+        again = model.predict_mask(xd).cpu().numpy()
+    finally:
+        model.set_option('mfma_mode', -1)
     assert np.array_equal(again, got[2])
 
 
@@ -239,6 +245,7 @@ def test_train_step_with_conv_x3d_matches_the_fp32_pipe(vr, net):
             model.load_state_dict(sd)
             model.to(torch.device('cuda:0'))
             model.train()
+            model.set_option('mfma_mode', 3)
             model.set_option('conv_x3d', x3d)
             model.set_option('train_winograd', wino)
             model.set_dropout_masks(None)                # (the library's generator is keyed on the number of forwards so far: off for an A / B)
@@ -247,6 +254,7 @@ def test_train_step_with_conv_x3d_matches_the_fp32_pipe(vr, net):
             res[name] = (float(loss), {k: v.numpy().astype(np.float64) for k, v in model.grads().items()})
     finally:
         model.set_option('conv_x3d', -1)
+        model.set_option('mfma_mode', -1)
         model.set_option('train_winograd', 1)
         model.set_dropout_masks(0)
         model.load_state_dict(sd)

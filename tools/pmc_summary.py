@@ -8,7 +8,7 @@ import sqlite3
 import sys
 
 FAMILY = 'conv family (conv_x3 + conv_wino + conv_dma + conv_thin + conv_ws + conv_mfma + wgrad)'
-KEYS = ('conv_x3_kernel', 'conv_x3h_kernel', 'conv_x3b_kernel', 'conv_x3p_kernel', 'conv_mfma_kernel', 'conv_ws_kernel', 'conv_dma_kernel', 'conv_dma_s2d_kernel',
+KEYS = ('conv_x3_kernel', 'conv_x3h_kernel', 'conv_x3d_kernel', 'conv_x3d_aspp_kernel', 'conv_x3b_kernel', 'conv_x3p_kernel', 'conv_mfma_kernel', 'conv_ws_kernel', 'conv_dma_kernel', 'conv_dma_s2d_kernel',
         'conv_thin_kernel', 'conv_wino_kernel', 'wgrad_ws_kernel', 'wgrad_mfma_kernel', 'wgrad_wino_kernel', 'wgrad_wino_r_kernel', 'wgrad_gemm_kernel')
 
 
