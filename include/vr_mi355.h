@@ -80,7 +80,10 @@ int vr_set_mode(vr_handle h, int training);
  *       the 1x1 weight-gradient GEMM round their operands to bf16 (RNE, in registers); accumulation, every stored tensor, the
  *       master weights and Adam stay fp32.   -1 = back to the handle's default (3, or VR_MFMA_MODE).
  * "mfma_bf16": 1 = "mfma_mode" 1; 0 = back to the handle's default mode.
- * "params_dirty": the parameter arena was written from outside (vr_param_arena).   */
+ * "params_dirty": the parameter arena was written from outside (vr_param_arena).
+ * "conv_x3d" (round 6, "mfma_mode" 3 only): the 16-column layers of 256-frame crops -- the ASPP branch convs (lib/layers.py:74-85) and
+ *   Encoder.conv2 of enc5 -- on the fp16 matrix pipe: 2 (default, also -1) with the four ASPP branches of a module in one launch,
+ *   1 one launch per conv, 0 the fp32-pipe kernels.   */
 int vr_set_option(vr_handle h, const char* name, int value);
 
 /* CascadedNet.forward (mode 0) / predict_mask (mode 1) / predict (mode 2)   lib/nets.py:82-141
