@@ -81,7 +81,13 @@ __device__ __forceinline__ void x3d_tile(const ConvArgs& a, const int pt, const 
         const int r = s >> 4, c = s & 15;
         const int hi = h0 - HH + r;
         const bool ok = s < NREAL && hi >= 0 && hi < a.Hin;
-        return ok ? (int)((unsigned)hi * sH4 + (unsigned)(c * 4)) : (int)0x80000000u;
+        // (product and sum kept apart: fused, hipcc emits v_mad_u64_u32 with a 64-bit addend whose undefined high half it parks in whatever
+        // register is free -- including the destination of a pixel load in flight; harmless, the low word is all that is used, but
+        // tools/asm_inflight_audit2.py rightly cannot tell)
+        unsigned off = (unsigned)hi * sH4;
+        asm volatile("" : "+v"(off));
+        off += (unsigned)(c * 4);
+        return ok ? (int)off : (int)0x80000000u;
     };
     // ---- weight operands: LDS order [tap][plane][m], source x3w[chunk][(tap * 2 + plane) * CoutPad + co0 + m] (conv_x3h.hip) ----
     unsigned woff0;
