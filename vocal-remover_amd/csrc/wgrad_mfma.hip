@@ -461,11 +461,32 @@ void wgrad_plan(WgradArgs& a, const ConvShape& s) {
     a.nchunks = (a.in.Cin + 31) / 32;
     a.nct = a.CoutPad / (32 * t.MB);
     a.part_stride = (long long)a.in.Cin * s.KS * s.KS * a.CoutPad;
-    long long P = 512 / ((long long)a.nchunks * a.nct);
-    if (P < 1) P = 1;
-    if (P > a.npt) P = a.npt;
-    const long long cap = (64LL << 20) / a.part_stride;       // scratch <= 256 MB
-    if (P > cap) P = cap < 1 ? 1 : cap;
+    const long long inner = (long long)a.nchunks * a.nct;
+    const long long cap = std::max<long long>(1, (64LL << 20) / a.part_stride);       // scratch <= 256 MB
+    // Round 6 (wgrad_wino_plan has the derivation): pixel range p runs on XCD p % 8 with its `inner` workgroups, an XCD has 32 CUs, so the
+    // busiest XCD makes ceil(ceil(P / 8) * inner / slots) passes of npt / P tiles each.  slots = 32 x the workgroups a CU holds: one for
+    // the warp-specialised kernel (2 x 55 KB of LDS), two for the dilated LDS-DMA kernel (60 - 76 KB).  The other shapes keep "512
+    // workgroups" (VR_WG_PTARGET restores it everywhere).
+    static const int ptarget = getenv("VR_WG_PTARGET") ? atoi(getenv("VR_WG_PTARGET")) : 0;
+    const bool dilated = s.dil_h != 1 || s.dil_w != 1;
+    const long long slots = t.ws ? 32 : (dilated ? 64 : 0);
+    long long P;
+    if (ptarget > 0 || slots == 0) {
+        P = (ptarget > 0 ? ptarget : 512) / inner;
+        if (P < 1) P = 1;
+        if (P > a.npt) P = a.npt;
+        if (P > cap) P = cap;
+    } else {
+        const long long pmax = std::min(std::min<long long>(a.npt, cap), std::max<long long>(8, 1024 / inner));
+        const double ovh = 4.0;
+        double best = 1e30;
+        P = 1;
+        for (long long c = 1; c <= pmax; ++c) {
+            const long long rounds = ((c + 7) / 8 * inner + slots - 1) / slots;
+            const double cost = (double)rounds * ((double)((a.npt + c - 1) / c) + ovh);
+            if (cost < best * 0.995) { best = cost; P = c; }
+        }
+    }
     a.P = (int)P;
 }
 

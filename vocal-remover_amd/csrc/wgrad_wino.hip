@@ -21,6 +21,7 @@
 //   * at the end the 16 frequencies of a (cout, cin) pair meet in LDS, A^T M A, and the 9 taps go to the block's
 //     partial slab [ci][tap][co]; wgrad_reduce_kernel (wgrad_mfma.hip) sums the P slabs deterministically.
 // fp32 throughout; the transforms only add and halve.
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -686,12 +687,32 @@ void wgrad_wino_plan(WgradArgs& a, int CB, int MT) {
     a.nchunks = (a.in.Cin + CB - 1) / CB;
     a.nct = a.CoutPad / MT;
     a.part_stride = (long long)a.in.Cin * 9 * a.CoutPad;
-    static const int ptarget = getenv("VR_WW_PTARGET") ? atoi(getenv("VR_WW_PTARGET")) : 512;
-    long long P = ptarget / ((long long)a.nchunks * a.nct);    // one workgroup per CU: two rounds of 256
-    if (P < 1) P = 1;
-    if (P > a.npt) P = a.npt;
-    const long long cap = (64LL << 20) / a.part_stride;       // scratch <= 256 MB
-    if (P > cap) P = cap < 1 ? 1 : cap;
+    const long long inner = (long long)a.nchunks * a.nct;
+    const long long cap = std::max<long long>(1, (64LL << 20) / a.part_stride);       // scratch <= 256 MB
+    static const int ptarget = getenv("VR_WW_PTARGET") ? atoi(getenv("VR_WW_PTARGET")) : 0;
+    long long P;
+    if (ptarget > 0) {                                        // rounds 2-5 (and the knob): ~ptarget workgroups whatever the shape
+        P = ptarget / inner;
+        if (P < 1) P = 1;
+        if (P > a.npt) P = a.npt;
+        if (P > cap) P = cap;
+    } else {
+        // Round 6: the number of pixel ranges from the dispatch geometry.  One workgroup per CU (139 / 104 KB of LDS; two for the 32 x 32 block), block b on XCD b % 8, 32 CUs
+        // per XCD; range p sits on XCD p % 8 with its `inner` (channel block, cout block) workgroups.  The busiest XCD carries
+        // ceil(P / 8) * inner workgroups = `rounds` passes over its 32 CUs, each as long as a range (npt / P chunks + the epilogue).  "512
+        // workgroups" gave a 192 -> 64 layer (inner = 3) P = 170: 66 workgroups on XCD 0 and 1 = THREE passes of 96 chunks where P = 168
+        // takes two (measured with VR_WW_PTARGET: 1905 -> 1400 us at P = 256, three passes of 64).  Ties: the fewest slabs.
+        const long long pmax = std::min(std::min<long long>(a.npt, cap), std::max<long long>(8, 1024 / inner));
+        const double ovh = 4.0;                               // epilogue + prologue of a workgroup, in chunks
+        double best = 1e30;
+        P = 1;
+        const long long slots = (CB == 32 && MT == 32) ? 64 : 32;     // (the 32 x 32 block's 70 KB of LDS fit a CU twice)
+        for (long long c = 1; c <= pmax; ++c) {
+            const long long rounds = ((c + 7) / 8 * inner + slots - 1) / slots;
+            const double cost = (double)rounds * ((double)((a.npt + c - 1) / c) + ovh);
+            if (cost < best * 0.995) { best = cost; P = c; }
+        }
+    }
     a.P = (int)P;
 }
 
