@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256, (DmaOcc<MT, TH, TW>::value)) void conv_dma_ker
         woff[i] = (unsigned)(((cl * KK + tap) * a.CoutPad + m4 * 4) * 4);
     }
 
+    const bool uniform_on = !(a.dbg & 8);                 // (VR_CONV_DBG=8: the per-channel form everywhere, for A / B)
     auto issue_chunk = [&](int k) {
         const int c0 = k * CK;
         const unsigned xs_b = lds0 + (unsigned)((k & 1) * Cfg::BUF * 4);
@@ -141,6 +142,41 @@ __global__ __launch_bounds__(256, (DmaOcc<MT, TH, TW>::value)) void conv_dma_ker
         unsigned long long f0p = (unsigned long long)a.src[0].p, f1p = (unsigned long long)a.src[1].p, f2p = (unsigned long long)a.src[2].p;
         asm volatile("" : "+s"(f0N), "+s"(f1N), "+s"(f2N), "+s"(f0C), "+s"(f1C), "+s"(f2C));
         asm volatile("" : "+s"(f0H), "+s"(f1H), "+s"(f2H), "+s"(f0p), "+s"(f1p), "+s"(f2p));
+        // Round 6: a chunk whose CK channels are all live and come from ONE source (nearly all of them) takes one descriptor -- the plane
+        // of its first channel -- and reaches channel cl through the SCALAR offset of the DMA (not part of the range check on gfx9, so
+        // padding lanes still read zeros).  The per-channel form below costs ~50 scalar instructions per channel (source select, 64-bit
+        // address arithmetic, descriptor, settle): eight channels per wave and chunk in the 1x1 tilings, beside 16 matrix instructions.
+        // (1x1 tilings only -- measured: 16-wide 1x1 0.51 -> 0.33 ms, 32-wide 0.28 -> 0.24 ms per inference step; with ONE channel per wave and
+        // chunk, the 3x3 stride-2 tilings were 6 - 15 % slower with it)
+        if constexpr (KS == 1) {
+            const int s0 = (c0 >= a.c1) + (c0 >= a.c2), s1 = (c0 + CK - 1 >= a.c1) + (c0 + CK - 1 >= a.c2);
+            if (uniform_on && c0 + CK <= a.Cin && s0 == s1) {
+                const int clc0 = c0 - (s0 == 0 ? 0 : (s0 == 1 ? a.c1 : a.c2));
+                const float* sp = reinterpret_cast<const float*>(s0 == 0 ? f0p : (s0 == 1 ? f1p : f2p));
+                const long long sN = s0 == 0 ? f0N : (s0 == 1 ? f1N : f2N);
+                const long long sC = s0 == 0 ? f0C : (s0 == 1 ? f1C : f2C);
+                const unsigned sH4 = (unsigned)(s0 == 0 ? f0H : (s0 == 1 ? f1H : f2H)) * 4u;
+                if ((unsigned long long)sC * 4ull * (unsigned long long)CK < 0x7FFFFFF0ull) {
+                    const i32x4 xr = make_rsrc(sp + (long long)n * sN + (long long)clc0 * sC, 0x7FFFFFF0u);
+                    const unsigned sC4 = (unsigned)(sC * 4);
+                    unsigned vo[NPASS];
+#pragma unroll
+                    for (int p = 0; p < NPASS; ++p) vo[p] = hrow[p] * sH4 + wcol4[p];
+#pragma unroll
+                    for (int cc = 0; cc < CPW; ++cc) {
+                        const int cl = wave + 4 * cc;
+                        const unsigned cb = xs_b + (unsigned)(cl * CSX * 4);
+                        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)cl * sC4));
+#pragma unroll
+                        for (int p = 0; p < NPASS; ++p) {
+                            if ((p + 1) * 64 <= NPIECE) dma16s(cb + p * 1024, vo[p], xr, so);
+                            else if (p * 64 + lane < NPIECE) dma16s(cb + p * 1024, vo[p], xr, so);
+                        }
+                    }
+                    return;
+                }
+            }
+        }
 #pragma unroll
         for (int cc = 0; cc < CPW; ++cc) {
             const int cl = wave + 4 * cc;
