@@ -9,6 +9,8 @@
 #include <cmath>
 #include <cstdlib>
 
+#include <algorithm>
+#include "conv_stage.h"
 #include "kernels.h"
 
 namespace vr {
@@ -107,6 +109,48 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
     if (threadIdx.x == 0) {
         a.part[((long long)blockIdx.x * a.C + c) * 2 + 0] = red[0] + red[2] + red[4] + red[6];
         a.part[((long long)blockIdx.x * a.C + c) * 2 + 1] = red[1] + red[3] + red[5] + red[7];
+    }
+}
+
+// pass 1 in the flat form of the apply pass (round 6): the plane (n, c) on blockIdx.y, ONE 16-byte load of z and of g per thread, 1024
+// elements per block -> one partial row per (sample, 1024-element piece) of a channel: part[((n * pieces + piece) * C + c) * 2 + {0,1}].
+// (The row-looped kernel above streams at ~4.2 TB/s, the flat apply pass below at 6.2: tools/hbm_rw.hip saw the same between a
+// grid-stride copy and one float4 per thread.)
+__global__ __launch_bounds__(256) void bn_bwd_reduce4p_kernel(BnBwdArgs a, int HQ) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int pc = blockIdx.y;
+    const int n = pc / a.C, c = pc - n * a.C;
+    float s1 = 0.f, s2 = 0.f;
+    if (idx < HQ) {
+        const int Q = a.W >> 2;
+        const int h = idx / Q, w = (idx - h * Q) * 4;
+        const long long off = (long long)n * a.sN + (long long)c * a.sC + (long long)h * a.sH + w;
+        const int ca = a.aff_bcast ? 0 : c;
+        const float sc = a.aff ? a.aff[2 * ca] : 1.f, sh = a.aff ? a.aff[2 * ca + 1] : 0.f;
+        const float pm = a.post ? a.post[n * a.C + c] : 1.f;
+        const float4 z4 = *reinterpret_cast<const float4*>(a.z + off);
+        const float4 g4 = *reinterpret_cast<const float4*>(a.g + off);
+        const float zz[4] = {z4.x, z4.y, z4.z, z4.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float dy = gg[j] * pm * dact(fmaf(zz[j], sc, sh), a.slope);
+            s1 += dy;
+            s2 = fmaf(dy, zz[j], s2);
+        }
+    }
+    // wave sums by DPP (valid in lanes 31 and 63 of the two halves), the four waves in a fixed order through LDS
+    s1 = half_wave_sum_dpp(s1);
+    s2 = half_wave_sum_dpp(s2);
+    __shared__ float red[8];
+    const int wave = threadIdx.x >> 6;
+    const float t1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s1), 31)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s1), 63));
+    const float t2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s2), 31)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s2), 63));
+    if ((threadIdx.x & 63) == 0) { red[wave * 2] = t1; red[wave * 2 + 1] = t2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const long long row = (long long)n * gridDim.x + blockIdx.x;
+        a.part[(row * a.C + c) * 2 + 0] = red[0] + red[2] + red[4] + red[6];
+        a.part[(row * a.C + c) * 2 + 1] = red[1] + red[3] + red[5] + red[7];
     }
 }
 
@@ -218,7 +262,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
     a.g[off] = a.coef ? fmaf(a.coef[3 * c], dy, fmaf(a.coef[3 * c + 1], z, a.coef[3 * c + 2])) : dy;
 }
 
-int bn_bwd_chunks(const BnBwdArgs& a) {
+static int bn_bwd_chunks_rows(const BnBwdArgs& a) {
     const long long per_c = (long long)a.N * a.H * a.W;
     long long ch = per_c / 16384;        // (round 5: 4096 / 8192 / 32768 elements per block measured the same: 2.64 - 2.76 ms per step)
     if (ch < 1) ch = 1;
@@ -226,13 +270,34 @@ int bn_bwd_chunks(const BnBwdArgs& a) {
     if (ch > (long long)a.N * a.H) ch = (long long)a.N * a.H;
     return (int)ch;
 }
+// the flat reduce (bn_bwd_reduce4p_kernel) by SHAPE: rows of whole 16-byte quads, planes on blockIdx.y, at least one full block per plane
+static bool bn_bwd_flat_shape(const BnBwdArgs& a) {
+    static const bool on = !(getenv("VR_BN_REDUCE_FLAT") && atoi(getenv("VR_BN_REDUCE_FLAT")) == 0);
+    const long long HQ = (long long)a.H * (a.W >> 2), planes = (long long)a.N * a.C;
+    return on && (a.W & 3) == 0 && (a.sH & 3) == 0 && (a.sC & 3) == 0 && (a.sN & 3) == 0 && planes <= 65535 && HQ >= 256 && HQ < (1LL << 30);
+}
+// partial rows per channel the scratch must hold (the kernel choice is re-made at launch time from the real pointers: the larger of the two)
+int bn_bwd_chunks(const BnBwdArgs& a) {
+    const int rows = bn_bwd_chunks_rows(a);
+    if (!bn_bwd_flat_shape(a)) return rows;
+    const long long flat = (long long)a.N * (((long long)a.H * (a.W >> 2) + 255) / 256);
+    return (int)std::max<long long>(rows, flat);
+}
 
 void launch_bn_bwd(const BnBwdArgs& a, hipStream_t st) {
     const double elems = (double)a.N * a.C * a.H * a.W;
     if (a.coef) {
-        const int nch = bn_bwd_chunks(a);
+        int nch = bn_bwd_chunks_rows(a);
         prof_note(0.0, 8.0 * elems);                         // reads z and g
-        VR_LAUNCH(bn_bwd_reduce_kernel, dim3(nch, a.C), dim3(256), 0, st, a);
+        const bool aligned = ((reinterpret_cast<uintptr_t>(a.z) | reinterpret_cast<uintptr_t>(a.g)) & 15) == 0;
+        if (bn_bwd_flat_shape(a) && aligned) {
+            const long long HQ = (long long)a.H * (a.W >> 2);
+            const unsigned pieces = (unsigned)((HQ + 255) / 256);
+            nch = (int)(a.N * (long long)pieces);
+            VR_LAUNCH(bn_bwd_reduce4p_kernel, dim3(pieces, (unsigned)((long long)a.N * a.C)), dim3(256), 0, st, a, (int)HQ);
+        } else {
+            VR_LAUNCH(bn_bwd_reduce_kernel, dim3(nch, a.C), dim3(256), 0, st, a);
+        }
         VR_HIP(hipGetLastError());
         VR_LAUNCH(bn_bwd_finalize_kernel, dim3(a.C), dim3(256), 0, st, a, nch);
         VR_HIP(hipGetLastError());
