@@ -119,25 +119,15 @@ struct EpiGroup {
                     const long long dH = VR_DST_FIELD(seg, sH);
                     const int dacc = VR_DST_FIELD(seg, accumulate);
                     const int dws = VR_DST_FIELD(seg, wshift);
-                    // (round 6: the old values of the row's WN pixels are fetched first, then the stores -- one memory round trip per row instead
-                    // of one per element; the data gradient of a conv whose sources are 2 + 8 + 16 channels wide runs through here entirely)
-                    float* q[WN];
-                    bool ok[WN];
-                    float old[WN];
-#pragma unroll
-                    for (int ni = 0; ni < WN; ++ni) {
-                        ok[ni] = co < e_Cout && hon[ni] < e_Hout && won[ni] < e_Wout && dp != nullptr;
-                        q[ni] = dp + (long long)n * dN + (long long)cod * dC + (long long)hon[ni] * dH + ((long long)won[ni] << dws);
-                        old[ni] = 0.f;
-                    }
-#pragma unroll
-                    for (int ni = 0; ni < WN; ++ni)
-                        if (ok[ni] && dacc) old[ni] = *q[ni];
 #pragma unroll
                     for (int ni = 0; ni < WN; ++ni) {
                         const float v = acc[mi][ni][r] + eb[j];
                         acc[mi][ni][r] = v;
-                        if (ok[ni]) *q[ni] = act_apply(fmaf(v, esc[j], esh[j]), eslope) + old[ni];
+                        if (co < e_Cout && hon[ni] < e_Hout && won[ni] < e_Wout && dp) {
+                            float* q = dp + (long long)n * dN + (long long)cod * dC + (long long)hon[ni] * dH + ((long long)won[ni] << dws);
+                            const float y = act_apply(fmaf(v, esc[j], esh[j]), eslope);
+                            *q = dacc ? *q + y : y;
+                        }
                     }
                 }
             }

@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libvr_mi355.so')
+# (VR_LIB_PATH: another build of the same library, for A / B runs of two builds in one gpurun call)
+LIB_PATH = os.environ.get('VR_LIB_PATH') or os.path.join(_HERE, 'libvr_mi355.so')
 
 c_f32p = ctypes.c_void_p
 c_i64p = ctypes.POINTER(ctypes.c_int64)
